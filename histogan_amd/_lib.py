@@ -1,0 +1,77 @@
+"""ctypes binding of libhistogan_hip.so (the C ABI declared in include/hg_hist.h).
+
+There is deliberately NO fallback: if the library is missing or fails to load,
+importing this module raises, and every op built on it is unusable.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libhistogan_hip.so')
+
+HG_METHOD = {'thresholding': 0, 'RBF': 1, 'inverse-quadratic': 2}
+HG_RESIZE_NONE, HG_RESIZE_BILINEAR, HG_RESIZE_SAMPLING = 0, 1, 2
+
+
+class HgHistParams(ctypes.Structure):
+    """struct hg_hist_params (include/hg_hist.h)."""
+    _fields_ = [
+        ('B', ctypes.c_int32), ('C', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
+        ('stride_b', ctypes.c_int64), ('stride_c', ctypes.c_int64),
+        ('stride_h', ctypes.c_int64), ('stride_w', ctypes.c_int64),
+        ('Hs', ctypes.c_int32), ('Ws', ctypes.c_int32),
+        ('resize_mode', ctypes.c_int32),
+        ('row_idx', ctypes.c_void_p), ('col_idx', ctypes.c_void_p),
+        ('h', ctypes.c_int32),
+        ('lo', ctypes.c_double), ('hi', ctypes.c_double),
+        ('method', ctypes.c_int32),
+        ('sigma', ctypes.c_double),
+        ('intensity_scale', ctypes.c_int32),
+        ('green_only', ctypes.c_int32),
+    ]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} not found: the gfx950 HIP library has not been built. '
+            f'Run `python -m histogan_amd.build` (needs hipcc). There is no CPU/PyTorch fallback.')
+    # torch must be imported first so that libamdhip64.so.7 resolves to the runtime torch uses
+    import torch  # noqa: F401
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    vp, sz, i32, i64, f32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    PP = ctypes.POINTER(HgHistParams)
+    lib.hg_version.restype = ctypes.c_int
+    lib.hg_version.argtypes = []
+    lib.hg_error_string.restype = ctypes.c_char_p
+    lib.hg_error_string.argtypes = [ctypes.c_int]
+    lib.hg_rgbuv_hist_workspace_bytes.restype = ctypes.c_int
+    lib.hg_rgbuv_hist_workspace_bytes.argtypes = [PP, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.hg_rgbuv_hist_fwd.restype = ctypes.c_int
+    lib.hg_rgbuv_hist_fwd.argtypes = [PP, vp, vp, vp, vp, sz, vp]
+    lib.hg_rgbuv_hist_bwd.restype = ctypes.c_int
+    lib.hg_rgbuv_hist_bwd.argtypes = [PP, vp, vp, vp, vp, vp, vp, sz, vp]
+    lib.hg_hellinger_workspace_bytes.restype = sz
+    lib.hg_hellinger_workspace_bytes.argtypes = [i64]
+    lib.hg_hellinger_fwd_bwd.restype = ctypes.c_int
+    lib.hg_hellinger_fwd_bwd.argtypes = [vp, vp, i64, i32, f32, vp, vp, vp, sz, vp]
+    return lib
+
+
+lib = _load()
+
+# every symbol include/hg_hist.h declares
+EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_fwd',
+           'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd')
+
+
+class HgError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib.hg_error_string(rc).decode()
+        # the two argument errors of the reference are bare Exceptions with these messages
+        # (histogram_classes/RGBuvHistBlock.py:90-93, 141-144)
+        raise HgError(f'{what}: {msg} (code {rc})')

@@ -1,0 +1,734 @@
+// hg_hist.hip -- RGB-uv colour histogram, forward + backward, hand-written for gfx950.
+//
+// Replaces the ~80-launch-per-image aten chain of the reference
+// (histogram_classes/RGBuvHistBlock.py:75-228) and its autograd replay by
+//   forward : k_hist_fwd  (MFMA split-K over pixels)  -> k_hist_reduce -> k_hist_normalize
+//   backward: k_hist_bwd_prep -> k_hist_bwd (MFMA, recompute-not-store) [-> resize adjoint]
+//
+// Maths:  with L_c = log(x_c + 1e-6), a = L_R-L_G, b = L_R-L_B, c = L_G-L_B,
+// Iy = sqrt(R^2+G^2+B^2+1e-6), k(.) the soft-bin kernel and bins b_i = linspace(lo,hi,h):
+//   plane0[i][j] = sum_n Iy k(a-b_i)  k(b-b_j)        (u,v) = ( a,  b)   RGBuvHistBlock.py:112-148
+//   plane1[i][j] = sum_n Iy k(-a-b_i) k(c-b_j)        (u,v) = (-a,  c)   RGBuvHistBlock.py:150-187
+//   plane2[i][j] = sum_n Iy k(-b-b_i) k(-c-b_j)       (u,v) = (-b, -c)   RGBuvHistBlock.py:190-222
+// Each plane is a rank-N contraction  (Iy*Ku)^T @ Kv  (h x N x h)  -> v_mfma_f32_32x32x2_f32 with
+// BOTH operands generated on the fly from 16 B of per-pixel state (a,b,c,Iy).  Because both MFMA
+// operands use the same lane->(bin = lane&31, pixel = lane>>5) map, one evaluated kernel value can
+// feed the A side of one plane and the B side of another.  With the mirrored bin table
+// b'_i = -b_(h-1-i) we have k(-a-b_i) = k(a-b'_(h-1-i)), so planes 1 and 2 are accumulated with
+// un-negated variables into index-flipped tiles and flipped back when the slab is written; for the
+// default symmetric boundary b' == b and only 3 kernel vectors per pixel are evaluated instead of 6.
+//
+// Precision: u is fp32 exactly as in the reference (fp32 log - fp32 log); the reference then
+// evaluates |u-b_i| in fp64.  Here t=(u-b_i)/sigma is formed as fma(u, 1/sigma, c_hi)+c_lo with
+// (c_hi,c_lo) a double-single split of -b_i/sigma, which keeps t to ~1e-7 relative without fp64;
+// thresholding compares in fp64 so its 0/1 weights are bit-identical to the reference's.
+// v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain (no reduced-precision path on gfx950).
+#include "hg_common.h"
+#include "../../include/hg_hist.h"
+
+#define HG_VERSION_NUM 100
+
+namespace {
+
+constexpr float kEps = 1e-6f;  // RGBuvHistBlock.py:26
+
+struct DevParams {
+  int B, C, H, W;
+  long long sb, sc, sh, sw;
+  int Hs, Ws, mode;
+  const int *rows, *cols;
+  int h, P, method, intensity, green;
+  int npix;
+  double lo, hi, step;      // bins: i*step+lo, last == hi  (np.linspace)
+  double inv_sigma_d;       // (double)(float)(1/sigma) -- pairs with inv_sigma
+  float inv_sigma;
+  double half_eps;          // thresholding: eps/2, eps=(|lo|+|hi|)/h  (RGBuvHistBlock.py:70-71,124)
+  float rscale_h, rscale_w; // bilinear: (float)H/Hs, (float)W/Ws
+  // backward: t = (u-lo)/sigma - i*(step/sigma), step/sigma split so that i*ds_hi is exact
+  double inv_sigma_x;       // exact 1/sigma in double
+  float ds_hi, ds_lo;
+  float dk_scale;           // -2/sigma
+};
+
+__device__ __forceinline__ double bin_center(const DevParams &P, int i) {
+  return (i == P.h - 1) ? P.hi : (double)i * P.step + P.lo;
+}
+
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+// Stage 0 (clamp + resize), RGBuvHistBlock.py:76-99.  n indexes the Hs x Ws sampled grid.
+__device__ __forceinline__ void sample_rgb(const DevParams &P, const float *xb, int n, float &r,
+                                           float &g, float &b) {
+  const int ys = n / P.Ws, xs = n - ys * P.Ws;
+  if (P.mode == HG_RESIZE_BILINEAR) {
+    // aten upsample_bilinear2d, align_corners=False: src = scale*(dst+0.5)-0.5, clamped at 0
+    float sy = fmaxf(P.rscale_h * ((float)ys + 0.5f) - 0.5f, 0.f);
+    float sx = fmaxf(P.rscale_w * ((float)xs + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)sy, P.H - 1), x0 = min((int)sx, P.W - 1);
+    const float ly = clamp01(sy - (float)y0), lx = clamp01(sx - (float)x0);
+    const int y1 = y0 + (y0 < P.H - 1 ? 1 : 0), x1 = x0 + (x0 < P.W - 1 ? 1 : 0);
+    const long long o00 = y0 * P.sh + x0 * P.sw, o01 = y0 * P.sh + x1 * P.sw;
+    const long long o10 = y1 * P.sh + x0 * P.sw, o11 = y1 * P.sh + x1 * P.sw;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float *pc = xb + c * P.sc;
+      const float p00 = clamp01(pc[o00]), p01 = clamp01(pc[o01]);
+      const float p10 = clamp01(pc[o10]), p11 = clamp01(pc[o11]);
+      v[c] = (1.f - ly) * ((1.f - lx) * p00 + lx * p01) + ly * ((1.f - lx) * p10 + lx * p11);
+    }
+    r = v[0]; g = v[1]; b = v[2];
+  } else {
+    int yy = ys, xx = xs;
+    if (P.mode == HG_RESIZE_SAMPLING) { yy = P.rows[ys]; xx = P.cols[xs]; }
+    const long long o = yy * P.sh + xx * P.sw;
+    r = clamp01(xb[o]); g = clamp01(xb[o + P.sc]); b = clamp01(xb[o + 2 * P.sc]);
+  }
+}
+
+// Stage 1 (projection), RGBuvHistBlock.py:104-115: three logs and three chroma differences.
+__device__ __forceinline__ void project(const DevParams &P, float r, float g, float b, float &a,
+                                        float &bb, float &c, float &iy) {
+  const float lr = logf(r + kEps), lg = logf(g + kEps), lb = logf(b + kEps);
+  a = lr - lg; bb = lr - lb; c = lg - lb;
+  iy = P.intensity ? sqrtf(((r * r + g * g) + b * b) + kEps) : 1.f;
+}
+
+struct BinC { float chi, clo; double bd; };
+
+// constants of bin i for the direct table (mirror=false) or the mirrored table b'_i = -b_(h-1-i)
+__device__ __forceinline__ BinC make_binc(const DevParams &P, int i, bool mirror) {
+  double bd = mirror ? -bin_center(P, P.h - 1 - i) : bin_center(P, i);
+  const double c = -bd * P.inv_sigma_d;
+  BinC r; r.chi = (float)c; r.clo = (float)(c - (double)r.chi); r.bd = bd;
+  return r;
+}
+
+template <int METHOD>
+__device__ __forceinline__ float kern_eval(const DevParams &P, float u, const BinC &bc) {
+  if constexpr (METHOD == HG_METHOD_THRESHOLDING) {
+    return (fabs((double)u - bc.bd) <= P.half_eps) ? 1.f : 0.f;
+  } else {
+    const float t = fmaf(u, P.inv_sigma, bc.chi) + bc.clo;
+    if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) return __builtin_amdgcn_rcpf(fmaf(t, t, 1.f));
+    else return expf(-(t * t));
+  }
+}
+
+__device__ __forceinline__ void lds_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ------------------------------------------------------------------------------------------------
+// Forward.  grid = (S splits, nbd*nbd output blocks, B images), 256 threads = 4 independent waves.
+// Each wave owns a contiguous run of `chunk` pixels and accumulates a (3 x BLK x BLK) partial
+// histogram block (BLK = 32*T) in 3*T*T MFMA accumulator tiles; the 4 waves are then summed through
+// LDS in fixed order and written as one slab  slabs[b][s][p][h][h]  (real bin order, flips undone).
+template <int T, int METHOD, bool SYM, bool DIAG>
+__global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const float *__restrict__ x,
+                                                     float *__restrict__ slabs, const int chunk) {
+  constexpr int BLK = 32 * T;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *stage = reinterpret_cast<float4 *>(smem);            // [4 waves][64 pixels]
+  float *red = reinterpret_cast<float *>(smem + 4 * 64 * 16);  // [3][BLK][BLK]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int nbd = (P.h + BLK - 1) / BLK;
+  const int bi = blockIdx.y / nbd, bj = blockIdx.y - bi * nbd;
+  const int b = blockIdx.z, s = blockIdx.x, S = gridDim.x;
+  const float *xb = x + (long long)b * P.sb;
+
+  // per-lane bin constants: A side = rows (i) of this block, B side = columns (j)
+  BinC cA[T], cAm[T], cB[T], cBm[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int i = BLK * bi + 32 * t + l31, j = BLK * bj + 32 * t + l31;
+    cA[t] = make_binc(P, i, false);
+    cB[t] = make_binc(P, j, false);
+    cAm[t] = make_binc(P, i, !SYM);
+    cBm[t] = make_binc(P, j, !SYM);
+  }
+
+  f32x16 acc[3][T][T];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < T; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][ti][tj][r] = 0.f;
+
+  const long long start = (long long)(s * 4 + wave) * chunk;
+  const int end = (int)min((long long)P.npix, start + chunk);
+  const bool green = P.green != 0;
+
+  float r_ = 0.f, g_ = 0.f, b_ = 0.f;
+  if (start + lane < end) sample_rgb(P, xb, (int)start + lane, r_, g_, b_);
+  for (int base = (int)start; base < end; base += 64) {
+    float a, bb, c, iy;
+    project(P, r_, g_, b_, a, bb, c, iy);
+    const bool valid = base + lane < end;
+    stage[wave * 64 + lane] = valid ? make_float4(a, bb, c, iy) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // prefetch the next 64 pixels while this batch is in the MFMA loop
+    if (base + 64 + lane < end) sample_rgb(P, xb, base + 64 + lane, r_, g_, b_);
+    lds_wave_sync();
+    const int steps = (min(64, end - base) + 1) >> 1;
+    for (int m = 0; m < steps; ++m) {
+      const float4 q = stage[wave * 64 + 2 * m + half];  // {a, b, c, weight}; broadcast per half-wave
+      float A0[T], A1[T], A2[T], B0[T], B1[T], B2[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float ka = kern_eval<METHOD>(P, q.x, cA[t]);
+        const float kbA = kern_eval<METHOD>(P, q.y, cAm[t]);
+        A0[t] = q.w * ka;
+        A1[t] = SYM ? A0[t] : q.w * kern_eval<METHOD>(P, q.x, cAm[t]);
+        A2[t] = q.w * kbA;
+        B0[t] = (SYM && DIAG) ? kbA : kern_eval<METHOD>(P, q.y, cB[t]);
+        B1[t] = kern_eval<METHOD>(P, q.z, cB[t]);
+        B2[t] = SYM ? B1[t] : kern_eval<METHOD>(P, q.z, cBm[t]);
+      }
+#pragma unroll
+      for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < T; ++tj) {
+          if (!green) acc[0][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[ti], B0[tj], acc[0][ti][tj], 0, 0, 0);
+          acc[1][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[ti], B1[tj], acc[1][ti][tj], 0, 0, 0);
+          if (!green) acc[2][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[ti], B2[tj], acc[2][ti][tj], 0, 0, 0);
+        }
+    }
+    lds_wave_sync();
+  }
+
+  // fixed-order sum of the 4 waves' tiles through LDS (deterministic)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int ti = 0; ti < T; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < T; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              // C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+              const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * half;
+              const int j = 32 * tj + l31;
+              float *d = &red[(p * BLK + i) * BLK + j];
+              if (w == 0) *d = acc[p][ti][tj][r]; else *d += acc[p][ti][tj][r];
+            }
+    }
+    __syncthreads();
+  }
+
+  // slab write: slabs[((b*S+s)*Pn + po)*h*h + oi*h + oj], undoing the index flips of planes 1, 2
+  const int h = P.h, Pn = P.P;
+  float *slab = slabs + ((long long)(b * S + s) * Pn) * h * h;
+  for (int e = threadIdx.x; e < 3 * BLK * BLK; e += 256) {
+    const int p = e / (BLK * BLK), rem = e - p * BLK * BLK;
+    const int il = rem / BLK, jl = rem - il * BLK;
+    const int I = BLK * bi + il, J = BLK * bj + jl;
+    if (I >= h || J >= h) continue;
+    if (green && p != 1) continue;
+    const int oi = (p == 0) ? I : h - 1 - I;
+    const int oj = (p == 2) ? h - 1 - J : J;
+    const int po = green ? 0 : p;
+    slab[((long long)po * h + oi) * h + oj] = red[e];
+  }
+}
+
+// Sum the S slabs of each image (fixed order), write the raw histogram and one partial total per block.
+__global__ __launch_bounds__(256) void k_hist_reduce(const float *__restrict__ slabs, float *__restrict__ raw,
+                                                     float *__restrict__ partials, int S, int n_per_img) {
+  __shared__ float sm4[4];
+  const int b = blockIdx.y;
+  const float *src = slabs + (long long)b * S * n_per_img;
+  float tot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = blockIdx.x * 1024 + k * 256 + threadIdx.x;
+    if (e < n_per_img) {
+      float v = 0.f;
+      for (int s = 0; s < S; ++s) v += src[(long long)s * n_per_img + e];
+      raw[(long long)b * n_per_img + e] = v;
+      tot += v;
+    }
+  }
+  tot = hg_block_sum_256(tot, sm4);
+  if (threadIdx.x == 0) partials[b * gridDim.x + blockIdx.x] = tot;
+}
+
+// Stage 4 (normalise), RGBuvHistBlock.py:224-228: hist / (sum + 1e-6); in place.
+__global__ __launch_bounds__(256) void k_hist_normalize(float *__restrict__ hist, const float *__restrict__ partials,
+                                                        float *__restrict__ sum_out, int n_per_img) {
+  const int b = blockIdx.y, np = gridDim.x;
+  float tot = 0.f;
+  for (int k = 0; k < np; ++k) tot += partials[b * np + k];
+  const float den = tot + kEps;
+  if (blockIdx.x == 0 && threadIdx.x == 0) sum_out[b] = den;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = blockIdx.x * 1024 + k * 256 + threadIdx.x;
+    if (e < n_per_img) hist[(long long)b * n_per_img + e] /= den;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward.  With S' = sum(raw)+1e-6 and out = raw/S':  dL/draw = Ghat = (G - <G,out>) / S'.
+// k_hist_bwd_prep writes Ghat in the accumulation layout of the forward (planes 1/2 index-flipped,
+// zero-padded to HP x HP), gh[b][3][HP][HP].
+__global__ __launch_bounds__(256) void k_hist_bwd_prep(const float *__restrict__ gout, const float *__restrict__ hist,
+                                                       const float *__restrict__ sums, float *__restrict__ gh,
+                                                       int h, int HP, int green) {
+  __shared__ float sm4[4];
+  const int b = blockIdx.x, Pn = green ? 1 : 3, n = Pn * h * h;
+  const float *g = gout + (long long)b * n, *o = hist + (long long)b * n;
+  float d = 0.f;
+  for (int e = threadIdx.x; e < n; e += 256) d += g[e] * o[e];
+  d = hg_block_sum_256(d, sm4);
+  const float inv = 1.f / sums[b];
+  float *dst = gh + (long long)b * 3 * HP * HP;
+  for (int e = threadIdx.x; e < 3 * HP * HP; e += 256) {
+    const int p = e / (HP * HP), rem = e - p * HP * HP;
+    const int I = rem / HP, J = rem - I * HP;
+    float v = 0.f;
+    if (I < h && J < h && (!green || p == 1)) {
+      const int oi = (p == 0) ? I : h - 1 - I;
+      const int oj = (p == 2) ? h - 1 - J : J;
+      const int po = green ? 0 : p;
+      v = (g[((long long)po * h + oi) * h + oj] - d) * inv;
+    }
+    dst[e] = v;
+  }
+}
+
+// bin permutation shared by the MFMA K index and the accumulator row index (see k_hist_bwd)
+__device__ __forceinline__ constexpr int beta0(int s) { return (s & 3) + 8 * ((s >> 2) & 3) + 32 * (s >> 4); }
+
+// Main backward kernel (symmetric boundary, h <= 32*T).  grid = (S, B); 4 waves, each takes rounds
+// of 32 pixels: lane l handles pixel (l&31) and the 16*T bins  beta0(s) + 4*(l>>5), s < 16*T.
+//   Wa[i] = sum_j G0[i][j] kb_j + G1f[i][j] kc_j      (rows indexed by a-bins)
+//   Wb[i] = sum_j G0[j][i] ka_j + G2f[i][j] kc_j      (rows indexed by b-bins)
+//   Wc[i] = sum_j G1f[j][i] ka_j + G2f[j][i] kb_j     (rows indexed by c-bins)
+// as D[bin][pixel] MFMA tiles (A = Ghat from LDS, B = kernel values generated in registers), then
+//   dL/da = Iy * sum_i k'(a-b_i) Wa[i]   (same for b, c),   dL/dIy = 1/2 sum_i (ka Wa + kb Wb + kc Wc)[i]
+//   dL_R = da+db, dL_G = -da+dc, dL_B = -db-dc,   dx_c = dL_c/(x_c+1e-6) + dIy x_c/Iy   
+template <int T, int METHOD>
+__global__ __launch_bounds__(256, 1) void k_hist_bwd(const DevParams P, const float *__restrict__ x,
+                                                     const float *__restrict__ gh, float *__restrict__ gdst,
+                                                     const int rounds_per_wave) {
+  constexpr int BLK = 32 * T, NS = 16 * T, LD = BLK + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *G = reinterpret_cast<float *>(smem);  // [3][BLK][LD]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, q = lane & 31;
+  const int b = blockIdx.y, s_ = blockIdx.x;
+  const float *xb = x + (long long)b * P.sb;
+  const bool green = P.green != 0;
+
+  {
+    const float *src = gh + (long long)b * 3 * BLK * BLK;
+    for (int e = threadIdx.x; e < 3 * BLK * BLK; e += 256) {
+      const int p = e / (BLK * BLK), rem = e - p * BLK * BLK;
+      const int i = rem / BLK, j = rem - i * BLK;
+      G[(p * BLK + i) * LD + j] = src[e];
+    }
+  }
+  __syncthreads();
+  const float *G0 = G, *G1 = G + BLK * LD, *G2 = G + 2 * BLK * LD;
+
+  const long long wstart = ((long long)(s_ * 4 + wave) * rounds_per_wave) * 32;
+  for (int rd = 0; rd < rounds_per_wave; ++rd) {
+    const long long n0 = wstart + (long long)rd * 32;
+    if (n0 >= P.npix) break;
+    const int n = (int)n0 + q;
+    const bool valid = n < P.npix;
+    float r_ = 0.f, g_ = 0.f, b_ = 0.f;
+    if (valid) sample_rgb(P, xb, n, r_, g_, b_);
+    float a, bb, c, iy;
+    project(P, r_, g_, b_, a, bb, c, iy);
+
+    // t_s = (u - lo - 4*half*step)/sigma - beta0(s)*step/sigma, double-single
+    float th[3], tl[3];
+    double ud[3] = {(double)a, (double)bb, (double)c};
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+      const double tb = (ud[v] - P.lo - (double)(4 * half) * P.step) * P.inv_sigma_x;
+      th[v] = (float)tb; tl[v] = (float)(tb - (double)th[v]);
+    }
+    auto eval = [&](int v, int s, float &t) -> float {
+      const int beta = beta0(s) + 4 * half;
+      if constexpr (METHOD == HG_METHOD_THRESHOLDING) {
+        t = 0.f;
+        return (fabs(ud[v] - bin_center(P, beta)) <= P.half_eps) ? 1.f : 0.f;
+      } else {
+        const float kf = -(float)beta0(s);
+        t = fmaf(kf, P.ds_hi, th[v]) + fmaf(kf, P.ds_lo, tl[v]);
+        if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) return __builtin_amdgcn_rcpf(fmaf(t, t, 1.f));
+        else return expf(-(t * t));
+      }
+    };
+
+    float k[3][NS];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { float t; k[v][s] = eval(v, s, t); }
+
+    f32x16 W[3][T];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) W[v][t][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int beta = beta0(s) + 4 * half;
+#pragma unroll
+      for (int rt = 0; rt < T; ++rt) {
+        const int row = 32 * rt + q;
+        if (!green) {
+          W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G0[row * LD + beta], k[1][s], W[0][rt], 0, 0, 0);
+          W[1][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G0[beta * LD + row], k[0][s], W[1][rt], 0, 0, 0);
+          W[1][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G2[row * LD + beta], k[2][s], W[1][rt], 0, 0, 0);
+          W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G2[beta * LD + row], k[1][s], W[2][rt], 0, 0, 0);
+        }
+        W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G1[row * LD + beta], k[2][s], W[0][rt], 0, 0, 0);
+        W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G1[beta * LD + row], k[0][s], W[2][rt], 0, 0, 0);
+      }
+    }
+
+    // epilogue: this lane holds W[v][t][r] for bin beta0(16t+r)+4*half of pixel q
+    float gsum[3] = {0.f, 0.f, 0.f}, isum = 0.f;
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        float t;
+        (void)eval(v, s, t);  // recompute t only (k kept); cheap VALU next to 64-cycle MFMAs
+        const float kv = k[v][s];
+        const float kw = kv * W[v][s >> 4][s & 15];
+        isum += kw;
+        if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) gsum[v] = fmaf(t * kv, kw, gsum[v]);
+        else if constexpr (METHOD == HG_METHOD_RBF) gsum[v] = fmaf(t, kw, gsum[v]);
+      }
+#pragma unroll
+    for (int v = 0; v < 3; ++v) gsum[v] += __shfl_xor(gsum[v], 32, 64);
+    isum += __shfl_xor(isum, 32, 64);
+
+    const float da = iy * P.dk_scale * gsum[0], db = iy * P.dk_scale * gsum[1], dc = iy * P.dk_scale * gsum[2];
+    const float dIy = P.intensity ? 0.5f * isum : 0.f;
+    const float dLr = da + db, dLg = dc - da, dLb = -db - dc;
+    float dr = dLr / (r_ + kEps), dg = dLg / (g_ + kEps), dbl = dLb / (b_ + kEps);
+    if (P.intensity) {
+      const float w = dIy / iy;
+      dr = fmaf(w, r_, dr); dg = fmaf(w, g_, dg); dbl = fmaf(w, b_, dbl);
+    }
+    if (valid && half == 0) {
+      if (P.mode == HG_RESIZE_NONE) {
+        // direct write to grad_x (B,C,H,W contiguous) with the clamp mask of RGBuvHistBlock.py:76
+        const int ys = n / P.Ws, xs = n - ys * P.Ws;
+        const long long xo = ys * P.sh + xs * P.sw;
+        const float xr = xb[xo], xg = xb[xo + P.sc], xbv = xb[xo + 2 * P.sc];
+        float *gb = gdst + ((long long)b * P.C) * P.npix + n;
+        gb[0] = (xr >= 0.f && xr <= 1.f) ? dr : 0.f;
+        gb[P.npix] = (xg >= 0.f && xg <= 1.f) ? dg : 0.f;
+        gb[2LL * P.npix] = (xbv >= 0.f && xbv <= 1.f) ? dbl : 0.f;
+      } else {
+        // gradient w.r.t. the resized (already clamped) image: gxs[b][3][Hs*Ws]
+        float *gb = gdst + ((long long)b * 3) * P.npix + n;
+        gb[0] = dr; gb[P.npix] = dg; gb[2LL * P.npix] = dbl;
+      }
+    }
+    if (valid && half == 1 && P.mode == HG_RESIZE_NONE) {
+      for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
+    }
+  }
+}
+
+// Adjoint of the bilinear resize (deterministic gather) fused with the clamp mask.
+// grad_x[b][c][y][x] = mask(x) * sum_{Y,X} wy(Y->y) wx(X->x) gxs[b][c][Y][X]
+__global__ __launch_bounds__(256) void k_bilinear_adjoint(const DevParams P, const float *__restrict__ x,
+                                                          const float *__restrict__ gxs, float *__restrict__ gx) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)P.B * P.H * P.W;
+  if (idx >= total) return;
+  const int xx = (int)(idx % P.W);
+  const int yy = (int)((idx / P.W) % P.H);
+  const int b = (int)(idx / ((long long)P.W * P.H));
+  const float inv_h = 1.f / P.rscale_h, inv_w = 1.f / P.rscale_w;
+  const int Ylo = max(0, (int)floorf(((float)yy - 0.5f) * inv_h - 0.5f) - 1);
+  const int Yhi = min(P.Hs - 1, (int)ceilf(((float)yy + 1.5f) * inv_h - 0.5f) + 1);
+  const int Xlo = max(0, (int)floorf(((float)xx - 0.5f) * inv_w - 0.5f) - 1);
+  const int Xhi = min(P.Ws - 1, (int)ceilf(((float)xx + 1.5f) * inv_w - 0.5f) + 1);
+  float acc[3] = {0.f, 0.f, 0.f};
+  const float *gb = gxs + (long long)b * 3 * P.npix;
+  for (int Y = Ylo; Y <= Yhi; ++Y) {
+    const float sy = fmaxf(P.rscale_h * ((float)Y + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)sy, P.H - 1);
+    const float ly = clamp01(sy - (float)y0);
+    const int y1 = y0 + (y0 < P.H - 1 ? 1 : 0);
+    float wy = 0.f;
+    if (y0 == yy) wy += 1.f - ly;
+    if (y1 == yy) wy += ly;
+    if (wy == 0.f) continue;
+    for (int X = Xlo; X <= Xhi; ++X) {
+      const float sx = fmaxf(P.rscale_w * ((float)X + 0.5f) - 0.5f, 0.f);
+      const int x0 = min((int)sx, P.W - 1);
+      const float lx = clamp01(sx - (float)x0);
+      const int x1 = x0 + (x0 < P.W - 1 ? 1 : 0);
+      float wx = 0.f;
+      if (x0 == xx) wx += 1.f - lx;
+      if (x1 == xx) wx += lx;
+      if (wx == 0.f) continue;
+      const float w = wy * wx;
+      const long long o = (long long)Y * P.Ws + X;
+      acc[0] = fmaf(w, gb[o], acc[0]);
+      acc[1] = fmaf(w, gb[o + P.npix], acc[1]);
+      acc[2] = fmaf(w, gb[o + 2LL * P.npix], acc[2]);
+    }
+  }
+  const float *xb = x + (long long)b * P.sb + yy * P.sh + xx * P.sw;
+  float *dst = gx + ((long long)b * P.C) * P.H * P.W + (long long)yy * P.W + xx;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float xv = xb[c * P.sc];
+    dst[(long long)c * P.H * P.W] = (xv >= 0.f && xv <= 1.f) ? acc[c] : 0.f;
+  }
+}
+
+// Adjoint of index_select sampling (RGBuvHistBlock.py:82-89): scatter-add (indices may repeat when
+// the image side is shorter than h), fused with the clamp mask.  grad_x pre-zeroed.
+__global__ __launch_bounds__(256) void k_sampling_adjoint(const DevParams P, const float *__restrict__ x,
+                                                          const float *__restrict__ gxs, float *__restrict__ gx) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)P.B * P.npix;
+  if (idx >= total) return;
+  const int n = (int)(idx % P.npix), b = (int)(idx / P.npix);
+  const int ys = n / P.Ws, xs = n - ys * P.Ws;
+  const int yy = P.rows[ys], xx = P.cols[xs];
+  const float *xb = x + (long long)b * P.sb + yy * P.sh + xx * P.sw;
+  float *dst = gx + ((long long)b * P.C) * P.H * P.W + (long long)yy * P.W + xx;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float xv = xb[c * P.sc];
+    if (xv >= 0.f && xv <= 1.f) atomicAdd(dst + (long long)c * P.H * P.W, gxs[((long long)b * 3 + c) * P.npix + n]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+struct Plan {
+  int T, BLK, nbd, HP;
+  int S_fwd, chunk;          // forward: splits per image, pixels per wave (multiple of 64)
+  int nparts;                // reduce blocks per image
+  int S_bwd, rounds;         // backward: WGs per image, 32-pixel rounds per wave
+  size_t slab_bytes, part_bytes, gh_bytes, gxs_bytes;
+};
+
+int validate(const hg_hist_params *p) {
+  if (!p) return HG_EINVAL;
+  if (p->B <= 0 || p->C < 3 || p->H <= 0 || p->W <= 0 || p->Hs <= 0 || p->Ws <= 0 || p->h <= 0) return HG_EINVAL;
+  if (p->method < 0 || p->method > 2) return HG_EMETHOD;
+  if (p->resize_mode < 0 || p->resize_mode > 2) return HG_ERESIZE;
+  if (p->resize_mode == HG_RESIZE_SAMPLING && (!p->row_idx || !p->col_idx)) return HG_EINVAL;
+  if (p->resize_mode == HG_RESIZE_NONE && (p->Hs != p->H || p->Ws != p->W)) return HG_EINVAL;
+  if (!(p->hi >= p->lo)) return HG_EINVAL;
+  if (p->method != HG_METHOD_THRESHOLDING && !(p->sigma > 0.0)) return HG_EINVAL;
+  if ((long long)p->Hs * p->Ws > 0x7fffffffLL) return HG_EINVAL;
+  return HG_OK;
+}
+
+Plan make_plan(const hg_hist_params *p) {
+  Plan pl;
+  pl.T = (p->h <= 32) ? 1 : 2;
+  pl.BLK = 32 * pl.T;
+  pl.nbd = (p->h + pl.BLK - 1) / pl.BLK;
+  pl.HP = pl.nbd * pl.BLK;
+  const long long npix = (long long)p->Hs * p->Ws;
+  const int P = p->green_only ? 1 : 3;
+  // forward: aim at ~2 workgroups per CU (256 CUs), >= 64 pixels per wave
+  const long long wg_fixed = (long long)p->B * pl.nbd * pl.nbd;
+  long long S = (512 + wg_fixed - 1) / wg_fixed;
+  const long long maxS = (npix + 255) / 256;
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  long long chunk = (npix + 4 * S - 1) / (4 * S);
+  chunk = (chunk + 63) / 64 * 64;
+  S = (npix + 4 * chunk - 1) / (4 * chunk);
+  pl.S_fwd = (int)S;
+  pl.chunk = (int)chunk;
+  const long long n_per_img = (long long)P * p->h * p->h;
+  pl.nparts = (int)((n_per_img + 1023) / 1024);
+  pl.slab_bytes = (size_t)p->B * S * n_per_img * sizeof(float);
+  pl.part_bytes = ((size_t)p->B * pl.nparts * sizeof(float) + 255) / 256 * 256;
+  // backward: 1 workgroup per CU, rounds of 32 pixels per wave
+  const long long rounds_total = (npix + 31) / 32;
+  long long Sb = (512 + p->B - 1) / p->B;
+  const long long maxSb = (rounds_total + 3) / 4;
+  if (Sb > maxSb) Sb = maxSb;
+  if (Sb < 1) Sb = 1;
+  long long rpw = (rounds_total + 4 * Sb - 1) / (4 * Sb);
+  Sb = (rounds_total + 4 * rpw - 1) / (4 * rpw);
+  pl.S_bwd = (int)Sb;
+  pl.rounds = (int)rpw;
+  pl.gh_bytes = (size_t)p->B * 3 * pl.HP * pl.HP * sizeof(float);
+  pl.gxs_bytes = (p->resize_mode == HG_RESIZE_NONE) ? 0 : ((size_t)p->B * 3 * npix * sizeof(float) + 255) / 256 * 256;
+  return pl;
+}
+
+DevParams make_dev(const hg_hist_params *p) {
+  DevParams d;
+  d.B = p->B; d.C = p->C; d.H = p->H; d.W = p->W;
+  d.sb = p->stride_b; d.sc = p->stride_c; d.sh = p->stride_h; d.sw = p->stride_w;
+  d.Hs = p->Hs; d.Ws = p->Ws; d.mode = p->resize_mode; d.rows = p->row_idx; d.cols = p->col_idx;
+  d.h = p->h; d.P = p->green_only ? 1 : 3; d.method = p->method;
+  d.intensity = p->intensity_scale ? 1 : 0; d.green = p->green_only ? 1 : 0;
+  d.npix = p->Hs * p->Ws;
+  d.lo = p->lo; d.hi = p->hi; d.step = (p->h > 1) ? (p->hi - p->lo) / (double)(p->h - 1) : 0.0;
+  const double sigma = (p->method == HG_METHOD_THRESHOLDING) ? 1.0 : p->sigma;
+  d.inv_sigma = (float)(1.0 / sigma);
+  d.inv_sigma_d = (double)d.inv_sigma;
+  d.half_eps = ((p->lo < 0 ? -p->lo : p->lo) + (p->hi < 0 ? -p->hi : p->hi)) / (double)p->h / 2.0;
+  d.rscale_h = (float)p->H / (float)p->Hs;
+  d.rscale_w = (float)p->W / (float)p->Ws;
+  d.inv_sigma_x = 1.0 / sigma;
+  const double ds = d.step / sigma;
+  union { float f; uint32_t u; } cv;
+  cv.f = (float)ds; cv.u &= 0xFFFFFF00u;  // 16 significant bits: beta0(s) (< 64) * ds_hi is exact in fp32
+  d.ds_hi = cv.f; d.ds_lo = (float)(ds - (double)d.ds_hi);
+  d.dk_scale = (float)(-2.0 / sigma);
+  return d;
+}
+
+template <int T, int METHOD>
+int launch_fwd_tm(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, hipStream_t st) {
+  const dim3 grid(pl.S_fwd, pl.nbd * pl.nbd, d.B), block(256);
+  const size_t lds = 4 * 64 * 16 + (size_t)3 * pl.BLK * pl.BLK * sizeof(float);
+  const bool diag = pl.nbd == 1;
+  if (sym && diag) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, true>), grid, block, lds, st, d, x, slabs, pl.chunk);
+  else if (sym) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, false>), grid, block, lds, st, d, x, slabs, pl.chunk);
+  else hipLaunchKernelGGL((k_hist_fwd<T, METHOD, false, false>), grid, block, lds, st, d, x, slabs, pl.chunk);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+template <int T>
+int launch_fwd_t(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, hipStream_t st) {
+  switch (d.method) {
+    case HG_METHOD_THRESHOLDING: return launch_fwd_tm<T, HG_METHOD_THRESHOLDING>(d, pl, sym, x, slabs, st);
+    case HG_METHOD_RBF: return launch_fwd_tm<T, HG_METHOD_RBF>(d, pl, sym, x, slabs, st);
+    default: return launch_fwd_tm<T, HG_METHOD_INVERSE_QUADRATIC>(d, pl, sym, x, slabs, st);
+  }
+}
+
+template <int T>
+int launch_bwd_t(const DevParams &d, const Plan &pl, const float *x, const float *gh, float *gdst, hipStream_t st) {
+  const dim3 grid(pl.S_bwd, d.B), block(256);
+  const size_t lds = (size_t)3 * pl.BLK * (pl.BLK + 1) * sizeof(float);
+  switch (d.method) {
+    case HG_METHOD_THRESHOLDING:
+      hipLaunchKernelGGL((k_hist_bwd<T, HG_METHOD_THRESHOLDING>), grid, block, lds, st, d, x, gh, gdst, pl.rounds); break;
+    case HG_METHOD_RBF:
+      hipLaunchKernelGGL((k_hist_bwd<T, HG_METHOD_RBF>), grid, block, lds, st, d, x, gh, gdst, pl.rounds); break;
+    default:
+      hipLaunchKernelGGL((k_hist_bwd<T, HG_METHOD_INVERSE_QUADRATIC>), grid, block, lds, st, d, x, gh, gdst, pl.rounds); break;
+  }
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hg_version(void) { return HG_VERSION_NUM; }
+
+const char *hg_error_string(int code) {
+  switch (code) {
+    case HG_OK: return "ok";
+    case HG_EINVAL: return "invalid argument";
+    case HG_EMETHOD: return "Wrong kernel method. It should be either thresholding, RBF, inverse-quadratic.";
+    case HG_ERESIZE: return "Wrong resizing method. It should be: interpolation or sampling.";
+    case HG_EWORKSPACE: return "workspace too small";
+    case HG_EUNSUPPORTED: return "configuration not supported by the gfx950 kernels";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+  }
+}
+
+int hg_rgbuv_hist_workspace_bytes(const hg_hist_params *p, size_t *fwd_bytes, size_t *bwd_bytes) {
+  const int rc = validate(p);
+  if (rc) return rc;
+  const Plan pl = make_plan(p);
+  if (fwd_bytes) *fwd_bytes = pl.part_bytes + pl.slab_bytes;
+  if (bwd_bytes) *bwd_bytes = pl.gxs_bytes + pl.gh_bytes;
+  return HG_OK;
+}
+
+int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, float *sum_out, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+  const int rc = validate(p);
+  if (rc) return rc;
+  if (!x || !hist_out || !sum_out || !workspace) return HG_EINVAL;
+  const Plan pl = make_plan(p);
+  if (workspace_bytes < pl.part_bytes + pl.slab_bytes) return HG_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const DevParams d = make_dev(p);
+  float *partials = (float *)workspace;
+  float *slabs = (float *)((char *)workspace + pl.part_bytes);
+  const bool sym = (p->lo == -p->hi);
+  int r = (pl.T == 1) ? launch_fwd_t<1>(d, pl, sym, x, slabs, st) : launch_fwd_t<2>(d, pl, sym, x, slabs, st);
+  if (r) return r;
+  const int n_per_img = d.P * d.h * d.h;
+  hipLaunchKernelGGL(k_hist_reduce, dim3(pl.nparts, d.B), dim3(256), 0, st, slabs, hist_out, partials, pl.S_fwd, n_per_img);
+  HG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_hist_normalize, dim3(pl.nparts, d.B), dim3(256), 0, st, hist_out, partials, sum_out, n_per_img);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+int hg_rgbuv_hist_bwd(const hg_hist_params *p, const float *x, const float *grad_out, const float *hist_out,
+                      const float *sum_out, float *grad_x, void *workspace, size_t workspace_bytes, void *stream) {
+  const int rc = validate(p);
+  if (rc) return rc;
+  if (!x || !grad_out || !hist_out || !sum_out || !grad_x || !workspace) return HG_EINVAL;
+  const Plan pl = make_plan(p);
+  if (workspace_bytes < pl.gxs_bytes + pl.gh_bytes) return HG_EWORKSPACE;
+  const bool sym = (p->lo == -p->hi);
+  if (!sym || pl.nbd != 1) return HG_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const DevParams d = make_dev(p);
+  float *gxs = (float *)workspace;
+  float *gh = (float *)((char *)workspace + pl.gxs_bytes);
+  hipLaunchKernelGGL(k_hist_bwd_prep, dim3(d.B), dim3(256), 0, st, grad_out, hist_out, sum_out, gh, d.h, pl.HP, d.green);
+  HG_LAUNCH_CHECK();
+  const size_t gx_bytes = (size_t)d.B * d.C * d.H * d.W * sizeof(float);
+  float *gdst = grad_x;
+  if (d.mode != HG_RESIZE_NONE) {
+    gdst = gxs;
+    if (d.mode == HG_RESIZE_SAMPLING || d.C > 3) {
+      hipError_t e = hipMemsetAsync(grad_x, 0, gx_bytes, st);
+      if (e != hipSuccess) return (int)e;
+    }
+  }
+  int r = (pl.T == 1) ? launch_bwd_t<1>(d, pl, x, gh, gdst, st) : launch_bwd_t<2>(d, pl, x, gh, gdst, st);
+  if (r) return r;
+  if (d.mode == HG_RESIZE_BILINEAR) {
+    const long long total = (long long)d.B * d.H * d.W;
+    hipLaunchKernelGGL(k_bilinear_adjoint, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, x, gxs, grad_x);
+    HG_LAUNCH_CHECK();
+  } else if (d.mode == HG_RESIZE_SAMPLING) {
+    const long long total = (long long)d.B * d.npix;
+    hipLaunchKernelGGL(k_sampling_adjoint, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, x, gxs, grad_x);
+    HG_LAUNCH_CHECK();
+  }
+  return HG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,164 @@
+"""RGB-uv histogram + Hellinger loss as torch.autograd Functions over the HIP C ABI.
+
+Host-side mirror of histogram_classes/RGBuvHistBlock.py:75-228 (forward) and of the autograd
+replay of it; Hellinger loss of histoGAN/histoGAN.py:957-960.  PyTorch is used only for device
+memory (caching allocator), the current stream and autograd plumbing.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import HgHistParams, check, lib
+
+_IDX_CACHE = {}
+
+
+def _sampling_idx(size, h, device):
+    """torch.LongTensor(np.linspace(0, size, h, endpoint=False)) of RGBuvHistBlock.py:82-87."""
+    key = (size, h, str(device))
+    t = _IDX_CACHE.get(key)
+    if t is None:
+        t = torch.from_numpy(np.linspace(0, size, h, endpoint=False).astype(np.int64).astype(np.int32)).to(device)
+        _IDX_CACHE[key] = t
+    return t
+
+
+class HistConfig:
+    """Immutable description of one RGBuvHistBlock (ctor args, RGBuvHistBlock.py:29-73)."""
+    __slots__ = ('h', 'insz', 'resizing', 'method', 'sigma', 'intensity_scale', 'lo', 'hi', 'green_only')
+
+    def __init__(self, h=64, insz=150, resizing='interpolation', method='inverse-quadratic', sigma=0.02,
+                 intensity_scale=True, hist_boundary=None, green_only=False):
+        if hist_boundary is None:
+            hist_boundary = [-3, 3]
+        hb = sorted(hist_boundary)
+        self.h, self.insz, self.resizing, self.method = int(h), insz, resizing, method
+        self.sigma = sigma
+        self.intensity_scale, self.green_only = bool(intensity_scale), bool(green_only)
+        self.lo, self.hi = float(hb[0]), float(hb[1])
+
+
+def _make_params(x, cfg):
+    if x.dim() != 4 or x.shape[1] < 3:
+        raise ValueError(f'expected (B, C>=3, H, W) input, got {tuple(x.shape)}')
+    if cfg.method not in _lib.HG_METHOD:
+        raise Exception(f'Wrong kernel method. It should be either thresholding, RBF,'
+                        f' inverse-quadratic. But the given value is {cfg.method}.')
+    B, C, H, W = x.shape
+    p = HgHistParams()
+    p.B, p.C, p.H, p.W = B, C, H, W
+    p.stride_b, p.stride_c, p.stride_h, p.stride_w = x.stride()
+    keep = []
+    if H > cfg.insz or W > cfg.insz:
+        if cfg.resizing == 'interpolation':
+            p.resize_mode, p.Hs, p.Ws = _lib.HG_RESIZE_BILINEAR, int(cfg.insz), int(cfg.insz)
+        elif cfg.resizing == 'sampling':
+            r, c = _sampling_idx(H, cfg.h, x.device), _sampling_idx(W, cfg.h, x.device)
+            keep = [r, c]
+            p.resize_mode, p.Hs, p.Ws = _lib.HG_RESIZE_SAMPLING, cfg.h, cfg.h
+            p.row_idx, p.col_idx = r.data_ptr(), c.data_ptr()
+        else:
+            raise Exception(f'Wrong resizing method. It should be: interpolation or sampling. '
+                            f'But the given value is {cfg.resizing}.')
+    else:
+        p.resize_mode, p.Hs, p.Ws = _lib.HG_RESIZE_NONE, H, W
+    p.h, p.lo, p.hi = cfg.h, cfg.lo, cfg.hi
+    p.method = _lib.HG_METHOD[cfg.method]
+    p.sigma = float(cfg.sigma) if cfg.method != 'thresholding' else 1.0
+    p.intensity_scale, p.green_only = int(cfg.intensity_scale), int(cfg.green_only)
+    return p, keep
+
+
+def _ws_bytes(p):
+    f, b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    check(lib.hg_rgbuv_hist_workspace_bytes(ctypes.byref(p), ctypes.byref(f), ctypes.byref(b)),
+          'hg_rgbuv_hist_workspace_bytes')
+    return f.value, b.value
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_gpu(x, what):
+    if not x.is_cuda:
+        raise RuntimeError(f'{what}: input is on {x.device}; the MI355X-native path has no CPU implementation')
+
+
+class RGBuvHistFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, cfg):
+        _require_gpu(x, 'RGBuvHistFunction')
+        x = x.detach()
+        if x.dtype != torch.float32:
+            x = x.float()
+        p, keep = _make_params(x, cfg)
+        fwd_b, _ = _ws_bytes(p)
+        with torch.cuda.device(x.device):
+            P = 1 if cfg.green_only else 3
+            out = torch.empty((p.B, P, cfg.h, cfg.h), dtype=torch.float32, device=x.device)
+            sums = torch.empty((p.B,), dtype=torch.float32, device=x.device)
+            ws = torch.empty((max(fwd_b, 4),), dtype=torch.uint8, device=x.device)
+            check(lib.hg_rgbuv_hist_fwd(ctypes.byref(p), x.data_ptr(), out.data_ptr(), sums.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), _stream(x.device)), 'hg_rgbuv_hist_fwd')
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, out, sums)
+        ctx._keep = keep
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, out, sums = ctx.saved_tensors
+        cfg = ctx.cfg
+        p, keep = _make_params(x, cfg)
+        _, bwd_b = _ws_bytes(p)
+        g = grad_out.detach()
+        if g.dtype != torch.float32:
+            g = g.float()
+        g = g.contiguous()
+        with torch.cuda.device(x.device):
+            gx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+            ws = torch.empty((max(bwd_b, 4),), dtype=torch.uint8, device=x.device)
+            check(lib.hg_rgbuv_hist_bwd(ctypes.byref(p), x.data_ptr(), g.data_ptr(), out.data_ptr(),
+                                        sums.data_ptr(), gx.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        _stream(x.device)), 'hg_rgbuv_hist_bwd')
+        return gx, None
+
+
+def rgbuv_hist(x, cfg):
+    """Differentiable RGB-uv histogram of x (B,C>=3,H,W) -> (B, 3|1, h, h), on x's GPU."""
+    return RGBuvHistFunction.apply(x, cfg)
+
+
+class HellingerFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, target, gen, alpha):
+        _require_gpu(gen, 'HellingerFunction')
+        t = target.detach().float().contiguous()
+        g = gen.detach().float().contiguous()
+        if t.shape != g.shape:
+            raise ValueError(f'shape mismatch {tuple(t.shape)} vs {tuple(g.shape)}')
+        n = g.numel()
+        with torch.cuda.device(g.device):
+            loss = torch.empty((), dtype=torch.float32, device=g.device)
+            grad = torch.empty_like(g)
+            wsb = lib.hg_hellinger_workspace_bytes(n)
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=g.device)
+            check(lib.hg_hellinger_fwd_bwd(t.data_ptr(), g.data_ptr(), n, g.shape[0], float(alpha),
+                                           loss.data_ptr(), grad.data_ptr(), ws.data_ptr(), wsb,
+                                           _stream(g.device)), 'hg_hellinger_fwd_bwd')
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        (grad,) = ctx.saved_tensors
+        return None, grad * gl, None
+
+
+def hellinger_loss(target_hist, gen_hist, alpha=1.0):
+    """alpha/sqrt(2) * sqrt(sum((sqrt(t)-sqrt(g))^2)) / B  (histoGAN/histoGAN.py:957-960).
+    Gradient flows to gen_hist only (the reference's d/d target is computed and never used)."""
+    return HellingerFunction.apply(target_hist, gen_hist, alpha)
