@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path benchmark (contract: one JSON line on rank 0).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hist|train]
+
+Workload `hist` (BASELINE.json configs[1]): RGB-uv histogram forward + Hellinger loss + backward
+on a resident synthetic batch 32x3x256x256 fp32, h=64, inverse-quadratic sigma=0.02, insz=256
+(N = 65 536 pixels per image).  One step = one pass over one batch.  Multi-GPU: every rank runs
+the same per-rank batch (weak scaling, no data-path collective -- images are independent,
+SURVEY.md section 8e); value = images of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = 'train images/sec (G+D step, 256², h=64) at 1/2/4/8 MI355X; hist-kernel HBM GB/s'
+FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: FP32 vector == FP32 MFMA (v_mfma_f32_32x32x2_f32)
+HBM_PEAK_GBPS = 8000.0
+
+
+def hist_workload(args, dev, rank, world):
+    from histogan_amd.hist import HistConfig, RGBuvHistFunction, hellinger_loss, rgbuv_hist
+    B, S, h = args.batch, args.size, args.bins
+    cfg = HistConfig(h=h, insz=S, method='inverse-quadratic', sigma=0.02)
+    g = torch.Generator(device='cpu').manual_seed(1000 + rank)
+    x = torch.rand(B, 3, S, S, generator=g).to(dev).requires_grad_(True)
+    with torch.no_grad():
+        target = rgbuv_hist(torch.rand(B, 3, S, S, generator=g).to(dev), cfg)
+
+    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(2)] for k in ('fwd', 'bwd')}
+    acc = {'fwd': 0.0, 'bwd': 0.0, 'n': 0}
+
+    def step(timed=False):
+        x.grad = None
+        if not timed:
+            hist = rgbuv_hist(x, cfg)
+            hellinger_loss(target, hist, alpha=2.0).backward()
+            return
+        # same work, split so that HIP events bracket the forward and the backward C-ABI calls
+        ev['fwd'][0].record()
+        hist = rgbuv_hist(x, cfg)
+        ev['fwd'][1].record()
+        loss = hellinger_loss(target, hist, alpha=2.0)
+        gh, = torch.autograd.grad(loss, hist)
+        ev['bwd'][0].record()
+        hist.backward(gh)
+        ev['bwd'][1].record()
+
+    def collect():
+        torch.cuda.synchronize()
+        acc['fwd'] += ev['fwd'][0].elapsed_time(ev['fwd'][1])
+        acc['bwd'] += ev['bwd'][0].elapsed_time(ev['bwd'][1])
+        acc['n'] += 1
+
+    N = S * S
+    flops_fwd = 6.0 * N * h * h * B            # 3 planes x 2 h^2 flop per pixel
+    flops_bwd = 2.0 * flops_fwd
+    bytes_fwd = B * (3 * N + 3 * h * h) * 4
+    bytes_bwd = B * (2 * 3 * N + 3 * h * h) * 4
+    info = dict(workload=f'rgbuv_hist fwd+hellinger+bwd {B}x3x{S}x{S} h={h} inverse-quadratic sigma=0.02 insz={S}',
+                batch_per_gpu=B, image_size=S, h=h, method='inverse-quadratic', parallelism=f'dp{world}')
+    return step, collect, acc, dict(flops_fwd=flops_fwd, flops_bwd=flops_bwd, bytes_fwd=bytes_fwd,
+                                    bytes_bwd=bytes_bwd), info, B
+
+
+def cpu_baseline(args):
+    """The oracle (port of the reference's PyTorch CPU path) on a bounded sample of the workload."""
+    from oracle import rgbuv_hist as O
+    S, h = args.size, args.bins
+    nimg = args.cpu_images
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(nimg, 3, S, S, generator=g)
+    tgt = O.rgbuv_hist(torch.rand(nimg, 3, S, S, generator=g), h=h, insz=S)
+    O.rgbuv_hist_fwd_bwd(x[:1], target=tgt[:1], h=h, insz=S)       # warm-up
+    t0 = time.perf_counter()
+    O.rgbuv_hist_fwd_bwd(x, target=tgt, alpha=2.0, h=h, insz=S)
+    dt = time.perf_counter() - t0
+    return dict(value=nimg / dt, unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{nimg} of the {args.batch} images ({nimg}x3x{S}x{S}), fwd+Hellinger+bwd, torch CPU '
+                       f'{torch.get_num_threads()} threads, {dt:.2f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='hist')
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--size', type=int, default=256)
+    ap.add_argument('--bins', type=int, default=64)
+    ap.add_argument('--cpu-images', type=int, default=4)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    step, collect, acc, work, info, units = hist_workload(args, dev, rank, world)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel durations: HIP events on the launch stream (torch current stream), separate short run
+    for _ in range(min(args.steps, 20)):
+        step(timed=True)
+        collect()
+    t_fwd = acc['fwd'] / acc['n'] * 1e-3
+    t_bwd = acc['bwd'] / acc['n'] * 1e-3
+
+    if rank == 0:
+        ach = work['flops_bwd'] / t_bwd / 1e12
+        out = {
+            'metric': METRIC, 'value': units * world * args.steps / dt, 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': info,
+            'roofline': {'kernel': 'k_hist_bwd', 'bound': 'mfma', 'achieved': ach, 'peak': FP32_PEAK_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': ach / FP32_PEAK_TFLOPS, 'traffic': None,
+                         'launch_ms': t_bwd * 1e3,
+                         'fwd': {'kernel': 'k_hist_fwd', 'achieved': work['flops_fwd'] / t_fwd / 1e12,
+                                 'frac': work['flops_fwd'] / t_fwd / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': t_fwd * 1e3}},
+            'hist_hbm_gbps_algorithmic': (work['bytes_fwd'] + work['bytes_bwd']) / (t_fwd + t_bwd) / 1e9,
+            'hist_hbm_frac_of_peak': (work['bytes_fwd'] + work['bytes_bwd']) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBPS,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

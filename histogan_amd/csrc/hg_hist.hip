@@ -89,9 +89,16 @@ __device__ __forceinline__ void sample_rgb(const DevParams &P, const float *xb, 
 // Stage 1 (projection), RGBuvHistBlock.py:104-115: three logs and three chroma differences.
 __device__ __forceinline__ void project(const DevParams &P, float r, float g, float b, float &a,
                                         float &bb, float &c, float &iy) {
-  const float lr = logf(r + kEps), lg = logf(g + kEps), lb = logf(b + kEps);
-  a = lr - lg; bb = lr - lb; c = lg - lb;
-  iy = P.intensity ? sqrtf(((r * r + g * g) + b * b) + kEps) : 1.f;
+  // The reference's CPU logf is correctly rounded for >99.9% of inputs (probe); an fp64 log rounded
+  // to fp32 reproduces it, where a 1-ulp device logf would perturb u by ~1e-7 and, through the
+  // ~50x sensitivity of k at |u-b| = sigma, move single weights by ~5e-6.  3 fp64 logs per pixel
+  // are noise next to 384+ MFMA cycles per pixel.
+  const float lr = (float)log((double)__fadd_rn(r, kEps));
+  const float lg = (float)log((double)__fadd_rn(g, kEps));
+  const float lb = (float)log((double)__fadd_rn(b, kEps));
+  a = __fsub_rn(lr, lg); bb = __fsub_rn(lr, lb); c = __fsub_rn(lg, lb);
+  // pow(I,2) summed left to right in fp32, no fma contraction (RGBuvHistBlock.py:105-108)
+  iy = P.intensity ? __fsqrt_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r, r), __fmul_rn(g, g)), __fmul_rn(b, b)), kEps)) : 1.f;
 }
 
 struct BinC { float chi, clo; double bd; };
