@@ -26,7 +26,7 @@ HBM_PEAK_GBPS = 8000.0
 
 
 def hist_workload(args, dev, rank, world):
-    from histogan_amd.hist import HistConfig, RGBuvHistFunction, hellinger_loss, rgbuv_hist
+    from histogan_amd.hist import HistConfig, hellinger_loss, rgbuv_hist
     B, S, h = args.batch, args.size, args.bins
     cfg = HistConfig(h=h, insz=S, method='inverse-quadratic', sigma=0.02)
     g = torch.Generator(device='cpu').manual_seed(1000 + rank)
@@ -34,30 +34,41 @@ def hist_workload(args, dev, rank, world):
     with torch.no_grad():
         target = rgbuv_hist(torch.rand(B, 3, S, S, generator=g).to(dev), cfg)
 
-    ev = {k: [torch.cuda.Event(enable_timing=True) for _ in range(2)] for k in ('fwd', 'bwd')}
-    acc = {'fwd': 0.0, 'bwd': 0.0, 'n': 0}
-
-    def step(timed=False):
+    def step():
         x.grad = None
-        if not timed:
-            hist = rgbuv_hist(x, cfg)
-            hellinger_loss(target, hist, alpha=2.0).backward()
-            return
-        # same work, split so that HIP events bracket the forward and the backward C-ABI calls
-        ev['fwd'][0].record()
         hist = rgbuv_hist(x, cfg)
-        ev['fwd'][1].record()
-        loss = hellinger_loss(target, hist, alpha=2.0)
-        gh, = torch.autograd.grad(loss, hist)
-        ev['bwd'][0].record()
-        hist.backward(gh)
-        ev['bwd'][1].record()
+        hellinger_loss(target, hist, alpha=2.0).backward()
 
-    def collect():
+    def time_kernels(iters):
+        """HIP events (on the stream the kernels are launched on) around the forward and the backward
+        C-ABI calls, buffers preallocated: pure device time of [k_hist_fwd + reduce + normalize] and
+        of [k_hist_bwd] -- the small kernels are <5 % of either (profiles/)."""
+        import ctypes
+        from histogan_amd import hist as HH
+        from histogan_amd._lib import lib, check
+        xd = x.detach()
+        p, keep = HH._make_params(xd, cfg)
+        fb, bb = HH._ws_bytes(p)
+        out = torch.empty(B, 3, h, h, device=dev)
+        sums = torch.empty(B, device=dev)
+        gx = torch.empty_like(xd)
+        gout = torch.rand(B, 3, h, h, device=dev) - 0.5
+        ws = torch.empty(max(fb, bb, 4), dtype=torch.uint8, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
+        for it in range(iters + 2):
+            e = evs[max(it - 2, 0)]
+            e[0].record()
+            check(lib.hg_rgbuv_hist_fwd(ctypes.byref(p), xd.data_ptr(), out.data_ptr(), sums.data_ptr(),
+                                        ws.data_ptr(), ws.numel(), st), 'fwd')
+            e[1].record()
+            check(lib.hg_rgbuv_hist_bwd(ctypes.byref(p), xd.data_ptr(), gout.data_ptr(), out.data_ptr(),
+                                        sums.data_ptr(), gx.data_ptr(), ws.data_ptr(), ws.numel(), st), 'bwd')
+            e[2].record()
         torch.cuda.synchronize()
-        acc['fwd'] += ev['fwd'][0].elapsed_time(ev['fwd'][1])
-        acc['bwd'] += ev['bwd'][0].elapsed_time(ev['bwd'][1])
-        acc['n'] += 1
+        tf = sum(e[0].elapsed_time(e[1]) for e in evs) / iters * 1e-3
+        tb = sum(e[1].elapsed_time(e[2]) for e in evs) / iters * 1e-3
+        return tf, tb
 
     N = S * S
     flops_fwd = 6.0 * N * h * h * B            # SURVEY 8(d): 3 planes x 2 h^2 flop per pixel
@@ -66,7 +77,7 @@ def hist_workload(args, dev, rank, world):
     bytes_bwd = B * (2 * 3 * N + 3 * h * h) * 4
     info = dict(workload=f'rgbuv_hist fwd+hellinger+bwd {B}x3x{S}x{S} h={h} inverse-quadratic sigma=0.02 insz={S}',
                 batch_per_gpu=B, image_size=S, h=h, method='inverse-quadratic', parallelism=f'dp{world}')
-    return step, collect, acc, dict(flops_fwd=flops_fwd, flops_bwd=flops_bwd, bytes_fwd=bytes_fwd,
+    return step, time_kernels, dict(flops_fwd=flops_fwd, flops_bwd=flops_bwd, bytes_fwd=bytes_fwd,
                                     bytes_bwd=bytes_bwd), info, B
 
 
@@ -111,7 +122,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    step, collect, acc, work, info, units = hist_workload(args, dev, rank, world)
+    step, time_kernels, work, info, units = hist_workload(args, dev, rank, world)
 
     for _ in range(args.warmup):
         step()
@@ -132,12 +143,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # per-kernel durations: HIP events on the launch stream (torch current stream), separate short run
-    for _ in range(min(args.steps, 20)):
-        step(timed=True)
-        collect()
-    t_fwd = acc['fwd'] / acc['n'] * 1e-3
-    t_bwd = acc['bwd'] / acc['n'] * 1e-3
+    t_fwd, t_bwd = time_kernels(min(max(args.steps, 5), 20))
 
     if rank == 0:
         ach = work['flops_bwd'] / t_bwd / 1e12

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libhistogan_hip.so')
+_TAG = os.environ.get('HG_LIB_TAG', '')  # experiment builds only (histogan_amd/build.py)
+LIB_PATH = os.path.join(_PKG, 'libhistogan_hip' + ('_' + _TAG if _TAG else '') + '.so')
 
 HG_METHOD = {'thresholding': 0, 'RBF': 1, 'inverse-quadratic': 2}
 HG_RESIZE_NONE, HG_RESIZE_BILINEAR, HG_RESIZE_SAMPLING = 0, 1, 2

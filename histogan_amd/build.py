@@ -13,8 +13,11 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, 'csrc')
 ROOT = os.path.dirname(PKG)
-LIB = os.path.join(PKG, 'libhistogan_hip.so')
-STAMP = os.path.join(PKG, '.libhistogan_hip.stamp')
+# experiment builds: HG_LIB_TAG=foo HG_CFLAGS='-DHG_BWD_WAVES=2' -> libhistogan_hip_foo.so (loaded when HG_LIB_TAG=foo)
+TAG = os.environ.get('HG_LIB_TAG', '')
+EXTRA = os.environ.get('HG_CFLAGS', '').split()
+LIB = os.path.join(PKG, 'libhistogan_hip' + ('_' + TAG if TAG else '') + '.so')
+STAMP = os.path.join(PKG, '.libhistogan_hip' + ('_' + TAG if TAG else '') + '.stamp')
 ARCH = 'gfx950'
 
 
@@ -26,6 +29,7 @@ def _digest():
     hsh = hashlib.sha256()
     files = sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h'))
     files += sorted(os.path.join(ROOT, 'include', f) for f in os.listdir(os.path.join(ROOT, 'include')))
+    hsh.update(' '.join(EXTRA).encode())
     for f in files:
         hsh.update(f.encode())
         with open(f, 'rb') as fh:
@@ -49,9 +53,9 @@ def build(force=False, verbose=False):
                 return LIB
     objs = []
     for src in sources():
-        obj = os.path.join(CSRC, os.path.basename(src)[:-4] + '.o')
+        obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ('_' + TAG if TAG else '') + '.o')
         cmd = [hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wall',
-               '-Wno-unused-function', '-I', os.path.join(ROOT, 'include'), '-c', src, '-o', obj]
+               '-Wno-unused-function', *EXTRA, '-I', os.path.join(ROOT, 'include'), '-c', src, '-o', obj]
         if verbose:
             cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
             print(' '.join(cmd), flush=True)

@@ -25,8 +25,25 @@
 // v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain (no reduced-precision path on gfx950).
 #include "hg_common.h"
 #include "../../include/hg_hist.h"
+#include <cstdlib>
 
-#define HG_VERSION_NUM 100
+#define HG_VERSION_NUM 101
+
+#ifndef HG_FWD_SCHED_GROUPS
+#define HG_FWD_SCHED_GROUPS 1
+#endif
+#ifndef HG_FWD_VALU_PER_MFMA
+#define HG_FWD_VALU_PER_MFMA 4
+#endif
+#ifndef HG_BWD_SCHED_GROUPS
+#define HG_BWD_SCHED_GROUPS 1
+#endif
+#ifndef HG_BWD_SCHED_BARRIER
+#define HG_BWD_SCHED_BARRIER 1
+#endif
+#ifndef HG_BWD_WAVES
+#define HG_BWD_WAVES 2  // min waves/SIMD the backward kernel is register-budgeted for
+#endif
 
 namespace {
 
@@ -122,6 +139,14 @@ __device__ __forceinline__ float kern_eval(const DevParams &P, float u, const Bi
   }
 }
 
+// MFMA operands of one K step (2 pixels): A side carries the Iy weight, B side is the bare kernel.
+template <int T>
+struct Ops { float A0[T], A1[T], A2[T], B0[T], B1[T], B2[T]; };
+
+// backward: operands of one K step (2 bins): 6*T A values (Ghat from LDS) + the 3 kernel values
+template <int T>
+struct BOps { float A[T][6]; float ka, kb, kc; };
+
 __device__ __forceinline__ void lds_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -133,7 +158,7 @@ __device__ __forceinline__ void lds_wave_sync() {
 // Each wave owns a contiguous run of `chunk` pixels and accumulates a (3 x BLK x BLK) partial
 // histogram block (BLK = 32*T) in 3*T*T MFMA accumulator tiles; the 4 waves are then summed through
 // LDS in fixed order and written as one slab  slabs[b][s][p][h][h]  (real bin order, flips undone).
-template <int T, int METHOD, bool SYM, bool DIAG>
+template <int T, int METHOD, bool SYM, bool DIAG, bool GREEN>
 __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const float *__restrict__ x,
                                                      float *__restrict__ slabs, const int chunk) {
   constexpr int BLK = 32 * T;
@@ -171,7 +196,21 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
 
   const long long start = (long long)(s * 4 + wave) * chunk;
   const int end = (int)min((long long)P.npix, start + chunk);
-  const bool green = P.green != 0;
+  constexpr bool green = GREEN;
+
+  auto make_ops = [&](const float4 &q, Ops<T> &o) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float ka = kern_eval<METHOD>(P, q.x, cA[t]);
+      const float kbA = kern_eval<METHOD>(P, q.y, cAm[t]);
+      o.A0[t] = q.w * ka;
+      o.A1[t] = SYM ? o.A0[t] : q.w * kern_eval<METHOD>(P, q.x, cAm[t]);
+      o.A2[t] = q.w * kbA;
+      o.B0[t] = (SYM && DIAG) ? kbA : kern_eval<METHOD>(P, q.y, cB[t]);
+      o.B1[t] = kern_eval<METHOD>(P, q.z, cB[t]);
+      o.B2[t] = SYM ? o.B1[t] : kern_eval<METHOD>(P, q.z, cBm[t]);
+    }
+  };
 
   float r_ = 0.f, g_ = 0.f, b_ = 0.f;
   if (start + lane < end) sample_rgb(P, xb, (int)start + lane, r_, g_, b_);
@@ -184,28 +223,38 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
     if (base + 64 + lane < end) sample_rgb(P, xb, base + 64 + lane, r_, g_, b_);
     lds_wave_sync();
     const int steps = (min(64, end - base) + 1) >> 1;
+    // Software-pipelined K loop: the operands of step m+1 (VALU: 3..6 kernel vectors) are generated
+    // while the 3*T*T MFMAs of step m (64 cycles each) occupy the matrix pipe; the sched_group
+    // barriers ask for a 1 MFMA : 4 VALU interleave so a single wave keeps the pipe fed.
+    Ops<T> cur;
+    make_ops(stage[wave * 64 + half], cur);
+    float4 q1 = stage[wave * 64 + 2 * min(1, steps - 1) + half];
     for (int m = 0; m < steps; ++m) {
-      const float4 q = stage[wave * 64 + 2 * m + half];  // {a, b, c, weight}; broadcast per half-wave
-      float A0[T], A1[T], A2[T], B0[T], B1[T], B2[T];
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const float ka = kern_eval<METHOD>(P, q.x, cA[t]);
-        const float kbA = kern_eval<METHOD>(P, q.y, cAm[t]);
-        A0[t] = q.w * ka;
-        A1[t] = SYM ? A0[t] : q.w * kern_eval<METHOD>(P, q.x, cAm[t]);
-        A2[t] = q.w * kbA;
-        B0[t] = (SYM && DIAG) ? kbA : kern_eval<METHOD>(P, q.y, cB[t]);
-        B1[t] = kern_eval<METHOD>(P, q.z, cB[t]);
-        B2[t] = SYM ? B1[t] : kern_eval<METHOD>(P, q.z, cBm[t]);
-      }
+      // LDS read two steps ahead: its latency is covered by a whole step of MFMAs even when the two
+      // waves of a SIMD run phase-locked (the matrix-pipe arbiter interleaves their MFMAs 1:1).
+      float4 q2 = stage[wave * 64 + 2 * min(m + 2, steps - 1) + half];  // {a, b, c, weight}; broadcast per half-wave
+      Ops<T> nxt;
+      make_ops(q1, nxt);
 #pragma unroll
       for (int ti = 0; ti < T; ++ti)
 #pragma unroll
         for (int tj = 0; tj < T; ++tj) {
-          if (!green) acc[0][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[ti], B0[tj], acc[0][ti][tj], 0, 0, 0);
-          acc[1][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[ti], B1[tj], acc[1][ti][tj], 0, 0, 0);
-          if (!green) acc[2][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(A2[ti], B2[tj], acc[2][ti][tj], 0, 0, 0);
+          if (!green) acc[0][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A0[ti], cur.B0[tj], acc[0][ti][tj], 0, 0, 0);
+          acc[1][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A1[ti], cur.B1[tj], acc[1][ti][tj], 0, 0, 0);
+          if (!green) acc[2][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A2[ti], cur.B2[tj], acc[2][ti][tj], 0, 0, 0);
         }
+#if HG_FWD_SCHED_GROUPS
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+      for (int i = 0; i < (green ? 1 : 3) * T * T; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, HG_FWD_VALU_PER_MFMA, 0);
+      }
+#endif
+      // pin: q2 is complete here (after a step's worth of MFMA issue), and is next iteration's q1
+      asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
+      q1 = q2;
+      cur = nxt;
     }
     lds_wave_sync();
   }
@@ -285,32 +334,9 @@ __global__ __launch_bounds__(256) void k_hist_normalize(float *__restrict__ hist
 
 // ------------------------------------------------------------------------------------------------
 // Backward.  With S' = sum(raw)+1e-6 and out = raw/S':  dL/draw = Ghat = (G - <G,out>) / S'.
-// k_hist_bwd_prep writes Ghat in the accumulation layout of the forward (planes 1/2 index-flipped,
-// zero-padded to HP x HP), gh[b][3][HP][HP].
-__global__ __launch_bounds__(256) void k_hist_bwd_prep(const float *__restrict__ gout, const float *__restrict__ hist,
-                                                       const float *__restrict__ sums, float *__restrict__ gh,
-                                                       int h, int HP, int green) {
-  __shared__ float sm4[4];
-  const int b = blockIdx.x, Pn = green ? 1 : 3, n = Pn * h * h;
-  const float *g = gout + (long long)b * n, *o = hist + (long long)b * n;
-  float d = 0.f;
-  for (int e = threadIdx.x; e < n; e += 256) d += g[e] * o[e];
-  d = hg_block_sum_256(d, sm4);
-  const float inv = 1.f / sums[b];
-  float *dst = gh + (long long)b * 3 * HP * HP;
-  for (int e = threadIdx.x; e < 3 * HP * HP; e += 256) {
-    const int p = e / (HP * HP), rem = e - p * HP * HP;
-    const int I = rem / HP, J = rem - I * HP;
-    float v = 0.f;
-    if (I < h && J < h && (!green || p == 1)) {
-      const int oi = (p == 0) ? I : h - 1 - I;
-      const int oj = (p == 2) ? h - 1 - J : J;
-      const int po = green ? 0 : p;
-      v = (g[((long long)po * h + oi) * h + oj] - d) * inv;
-    }
-    dst[e] = v;
-  }
-}
+// Every workgroup of k_hist_bwd rebuilds Ghat for its image in LDS (planes 1/2 index-flipped and
+// zero-padded to BLK x BLK, the accumulation layout of the forward): 2 x 48 KB of L2 reads per
+// workgroup instead of a separate low-occupancy prep launch.
 
 // bin permutation shared by the MFMA K index and the accumulator row index (see k_hist_bwd)
 __device__ __forceinline__ constexpr int beta0(int s) { return (s & 3) + 8 * ((s >> 2) & 3) + 32 * (s >> 4); }
@@ -323,10 +349,12 @@ __device__ __forceinline__ constexpr int beta0(int s) { return (s & 3) + 8 * ((s
 // as D[bin][pixel] MFMA tiles (A = Ghat from LDS, B = kernel values generated in registers), then
 //   dL/da = Iy * sum_i k'(a-b_i) Wa[i]   (same for b, c),   dL/dIy = 1/2 sum_i (ka Wa + kb Wb + kc Wc)[i]
 //   dL_R = da+db, dL_G = -da+dc, dL_B = -db-dc,   dx_c = dL_c/(x_c+1e-6) + dIy x_c/Iy   
-template <int T, int METHOD>
-__global__ __launch_bounds__(256, 1) void k_hist_bwd(const DevParams P, const float *__restrict__ x,
-                                                     const float *__restrict__ gh, float *__restrict__ gdst,
-                                                     const int rounds_per_wave) {
+template <int T, int METHOD, bool GREEN>
+__global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams P, const float *__restrict__ x,
+                                                                const float *__restrict__ gout,
+                                                                const float *__restrict__ hist,
+                                                                const float *__restrict__ sums,
+                                                                float *__restrict__ gdst, const int rounds_per_wave) {
   constexpr int BLK = 32 * T, NS = 16 * T, LD = BLK + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *G = reinterpret_cast<float *>(smem);  // [3][BLK][LD]
@@ -335,14 +363,26 @@ __global__ __launch_bounds__(256, 1) void k_hist_bwd(const DevParams P, const fl
   const int half = lane >> 5, q = lane & 31;
   const int b = blockIdx.y, s_ = blockIdx.x;
   const float *xb = x + (long long)b * P.sb;
-  const bool green = P.green != 0;
+  constexpr bool green = GREEN;
 
   {
-    const float *src = gh + (long long)b * 3 * BLK * BLK;
+    const int h = P.h, n = P.P * h * h;
+    const float *g = gout + (long long)b * n, *o = hist + (long long)b * n;
+    float d = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) d = fmaf(g[e], o[e], d);
+    d = hg_block_sum_256(d, G);  // <G, out>; G's first 16 B are scratch until the fill below
+    const float inv = 1.f / sums[b];
     for (int e = threadIdx.x; e < 3 * BLK * BLK; e += 256) {
       const int p = e / (BLK * BLK), rem = e - p * BLK * BLK;
-      const int i = rem / BLK, j = rem - i * BLK;
-      G[(p * BLK + i) * LD + j] = src[e];
+      const int I = rem / BLK, J = rem - I * BLK;
+      float v = 0.f;
+      if (I < h && J < h && (!green || p == 1)) {
+        const int oi = (p == 0) ? I : h - 1 - I;
+        const int oj = (p == 2) ? h - 1 - J : J;
+        const int po = green ? 0 : p;
+        v = (g[((long long)po * h + oi) * h + oj] - d) * inv;
+      }
+      G[(p * BLK + I) * LD + J] = v;
     }
   }
   __syncthreads();
@@ -380,12 +420,6 @@ __global__ __launch_bounds__(256, 1) void k_hist_bwd(const DevParams P, const fl
       }
     };
 
-    float k[3][NS];
-#pragma unroll
-    for (int v = 0; v < 3; ++v)
-#pragma unroll
-      for (int s = 0; s < NS; ++s) { float t; k[v][s] = eval(v, s, t); }
-
     f32x16 W[3][T];
 #pragma unroll
     for (int v = 0; v < 3; ++v)
@@ -394,36 +428,100 @@ __global__ __launch_bounds__(256, 1) void k_hist_bwd(const DevParams P, const fl
 #pragma unroll
         for (int r = 0; r < 16; ++r) W[v][t][r] = 0.f;
 
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int beta = beta0(s) + 4 * half;
+    // Kernel values are generated just in time (3 evaluations per 6*T MFMAs) and NOT kept: the
+    // epilogue re-evaluates them bit-identically, which keeps the kernel at W (48*T regs) + temporaries
+    // so that several waves per SIMD can overlap one wave's VALU phases with another's MFMAs.
+    // MFMA loop: a REAL loop over the 16*T K-steps (2 bins each).  Fully unrolled, the compiler hoists
+    // the (round-invariant) LDS operand reads and sinks the chain-free MFMA intrinsics below them,
+    // which costs >200 spilled VGPRs; one 6*T-MFMA body (384*T cycles) per iteration needs no unroll.
+    auto make_bops = [&](int s, BOps<T> &o) {
+      const int b0 = (s & 3) + 8 * ((s >> 2) & 3) + 32 * (s >> 4);
+      const int beta = b0 + 4 * half;
 #pragma unroll
       for (int rt = 0; rt < T; ++rt) {
         const int row = 32 * rt + q;
         if (!green) {
-          W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G0[row * LD + beta], k[1][s], W[0][rt], 0, 0, 0);
-          W[1][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G0[beta * LD + row], k[0][s], W[1][rt], 0, 0, 0);
-          W[1][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G2[row * LD + beta], k[2][s], W[1][rt], 0, 0, 0);
-          W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G2[beta * LD + row], k[1][s], W[2][rt], 0, 0, 0);
+          o.A[rt][0] = G0[row * LD + beta];
+          o.A[rt][1] = G0[beta * LD + row];
+          o.A[rt][2] = G2[beta * LD + row];
+          o.A[rt][3] = G2[row * LD + beta];
         }
-        W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G1[row * LD + beta], k[2][s], W[0][rt], 0, 0, 0);
-        W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(G1[beta * LD + row], k[0][s], W[2][rt], 0, 0, 0);
+        o.A[rt][4] = G1[row * LD + beta];
+        o.A[rt][5] = G1[beta * LD + row];
       }
+      if constexpr (METHOD == HG_METHOD_THRESHOLDING) {
+        const double bc = bin_center(P, beta);
+        o.ka = (fabs(ud[0] - bc) <= P.half_eps) ? 1.f : 0.f;
+        o.kb = (fabs(ud[1] - bc) <= P.half_eps) ? 1.f : 0.f;
+        o.kc = (fabs(ud[2] - bc) <= P.half_eps) ? 1.f : 0.f;
+      } else {
+        const float kf = -(float)b0;
+        const float ta = fmaf(kf, P.ds_hi, th[0]) + fmaf(kf, P.ds_lo, tl[0]);
+        const float tb = fmaf(kf, P.ds_hi, th[1]) + fmaf(kf, P.ds_lo, tl[1]);
+        const float tc = fmaf(kf, P.ds_hi, th[2]) + fmaf(kf, P.ds_lo, tl[2]);
+        if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) {
+          o.ka = __builtin_amdgcn_rcpf(fmaf(ta, ta, 1.f));
+          o.kb = __builtin_amdgcn_rcpf(fmaf(tb, tb, 1.f));
+          o.kc = __builtin_amdgcn_rcpf(fmaf(tc, tc, 1.f));
+        } else {
+          o.ka = expf(-(ta * ta)); o.kb = expf(-(tb * tb)); o.kc = expf(-(tc * tc));
+        }
+      }
+    };
+    BOps<T> cur;
+    make_bops(0, cur);
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+      BOps<T> nxt;
+      make_bops(min(s + 1, NS - 1), nxt);  // LDS reads + 3 kernel evaluations for the next K step
+#pragma unroll
+      for (int rt = 0; rt < T; ++rt) {
+        if (!green) {
+          W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][0], cur.kb, W[0][rt], 0, 0, 0);
+          W[1][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][1], cur.ka, W[1][rt], 0, 0, 0);
+          W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][2], cur.kb, W[2][rt], 0, 0, 0);
+          W[1][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][3], cur.kc, W[1][rt], 0, 0, 0);
+        }
+        W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][4], cur.kc, W[0][rt], 0, 0, 0);
+        W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][5], cur.ka, W[2][rt], 0, 0, 0);
+      }
+#if HG_BWD_SCHED_GROUPS
+      // all LDS operand reads of the next step first, then MFMAs with the 3 evaluations in their shadow
+      __builtin_amdgcn_sched_group_barrier(0x100, 6 * T, 0);
+#pragma unroll
+      for (int i = 0; i < (green ? 2 : 6) * T; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      }
+#endif
+      // pin: the next step's operands are complete here, after a step's worth of MFMA issue; without
+      // it the compiler rotates the loop and every MFMA waits on an LDS read issued just before it
+#pragma unroll
+      for (int rt = 0; rt < T; ++rt)
+#pragma unroll
+        for (int i = green ? 4 : 0; i < 6; ++i) asm volatile("" : "+v"(nxt.A[rt][i]));
+      cur = nxt;
     }
 
-    // epilogue: this lane holds W[v][t][r] for bin beta0(16t+r)+4*half of pixel q
+    // epilogue: this lane holds W[v][t][r] for bin beta0(16t+r)+4*half of pixel q.
+    // The empty asm makes the eval inputs opaque so the compiler re-evaluates (4 VALU ops each)
+    // instead of keeping 2 x 48*T values alive across the MFMA loop (CSE would cost ~190 VGPRs).
+#pragma unroll
+    for (int v = 0; v < 3; ++v) asm volatile("" : "+v"(th[v]), "+v"(tl[v]), "+v"(ud[v]));
     float gsum[3] = {0.f, 0.f, 0.f}, isum = 0.f;
 #pragma unroll
     for (int v = 0; v < 3; ++v)
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         float t;
-        (void)eval(v, s, t);  // recompute t only (k kept); cheap VALU next to 64-cycle MFMAs
-        const float kv = k[v][s];
+        const float kv = eval(v, s, t);
         const float kw = kv * W[v][s >> 4][s & 15];
         isum += kw;
         if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) gsum[v] = fmaf(t * kv, kw, gsum[v]);
         else if constexpr (METHOD == HG_METHOD_RBF) gsum[v] = fmaf(t, kw, gsum[v]);
+#if HG_BWD_SCHED_BARRIER
+        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the re-evaluations from being hoisted en bloc
+#endif
       }
 #pragma unroll
     for (int v = 0; v < 3; ++v) gsum[v] += __shfl_xor(gsum[v], 32, 64);
@@ -562,7 +660,9 @@ Plan make_plan(const hg_hist_params *p) {
   const int P = p->green_only ? 1 : 3;
   // forward: aim at ~2 workgroups per CU (256 CUs), >= 64 pixels per wave
   const long long wg_fixed = (long long)p->B * pl.nbd * pl.nbd;
-  long long S = (512 + wg_fixed - 1) / wg_fixed;
+  long long target = 512;
+  if (const char *e = getenv("HG_FWD_WGS")) target = atoll(e) > 0 ? atoll(e) : target;  // tuning knob
+  long long S = (target + wg_fixed - 1) / wg_fixed;
   const long long maxS = (npix + 255) / 256;
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
@@ -577,7 +677,9 @@ Plan make_plan(const hg_hist_params *p) {
   pl.part_bytes = ((size_t)p->B * pl.nparts * sizeof(float) + 255) / 256 * 256;
   // backward: 1 workgroup per CU, rounds of 32 pixels per wave
   const long long rounds_total = (npix + 31) / 32;
-  long long Sb = (512 + p->B - 1) / p->B;
+  long long targetb = 512;
+  if (const char *e = getenv("HG_BWD_WGS")) targetb = atoll(e) > 0 ? atoll(e) : targetb;  // tuning knob
+  long long Sb = (targetb + p->B - 1) / p->B;
   const long long maxSb = (rounds_total + 3) / 4;
   if (Sb > maxSb) Sb = maxSb;
   if (Sb < 1) Sb = 1;
@@ -585,7 +687,7 @@ Plan make_plan(const hg_hist_params *p) {
   Sb = (rounds_total + 4 * rpw - 1) / (4 * rpw);
   pl.S_bwd = (int)Sb;
   pl.rounds = (int)rpw;
-  pl.gh_bytes = (size_t)p->B * 3 * pl.HP * pl.HP * sizeof(float);
+  pl.gh_bytes = 256;  // (unused; keeps the workspace pointer non-empty)
   pl.gxs_bytes = (p->resize_mode == HG_RESIZE_NONE) ? 0 : ((size_t)p->B * 3 * npix * sizeof(float) + 255) / 256 * 256;
   return pl;
 }
@@ -614,16 +716,22 @@ DevParams make_dev(const hg_hist_params *p) {
   return d;
 }
 
-template <int T, int METHOD>
-int launch_fwd_tm(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, hipStream_t st) {
+template <int T, int METHOD, bool GREEN>
+int launch_fwd_tmg(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, hipStream_t st) {
   const dim3 grid(pl.S_fwd, pl.nbd * pl.nbd, d.B), block(256);
   const size_t lds = 4 * 64 * 16 + (size_t)3 * pl.BLK * pl.BLK * sizeof(float);
   const bool diag = pl.nbd == 1;
-  if (sym && diag) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, true>), grid, block, lds, st, d, x, slabs, pl.chunk);
-  else if (sym) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, false>), grid, block, lds, st, d, x, slabs, pl.chunk);
-  else hipLaunchKernelGGL((k_hist_fwd<T, METHOD, false, false>), grid, block, lds, st, d, x, slabs, pl.chunk);
+  if (sym && diag) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, true, GREEN>), grid, block, lds, st, d, x, slabs, pl.chunk);
+  else if (sym) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, false, GREEN>), grid, block, lds, st, d, x, slabs, pl.chunk);
+  else hipLaunchKernelGGL((k_hist_fwd<T, METHOD, false, false, GREEN>), grid, block, lds, st, d, x, slabs, pl.chunk);
   HG_LAUNCH_CHECK();
   return HG_OK;
+}
+
+template <int T, int METHOD>
+int launch_fwd_tm(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, hipStream_t st) {
+  return d.green ? launch_fwd_tmg<T, METHOD, true>(d, pl, sym, x, slabs, st)
+                 : launch_fwd_tmg<T, METHOD, false>(d, pl, sym, x, slabs, st);
 }
 
 template <int T>
@@ -635,20 +743,25 @@ int launch_fwd_t(const DevParams &d, const Plan &pl, bool sym, const float *x, f
   }
 }
 
-template <int T>
-int launch_bwd_t(const DevParams &d, const Plan &pl, const float *x, const float *gh, float *gdst, hipStream_t st) {
+template <int T, int METHOD>
+int launch_bwd_tm(const DevParams &d, const Plan &pl, const float *x, const float *gout, const float *hist,
+                  const float *sums, float *gdst, hipStream_t st) {
   const dim3 grid(pl.S_bwd, d.B), block(256);
   const size_t lds = (size_t)3 * pl.BLK * (pl.BLK + 1) * sizeof(float);
-  switch (d.method) {
-    case HG_METHOD_THRESHOLDING:
-      hipLaunchKernelGGL((k_hist_bwd<T, HG_METHOD_THRESHOLDING>), grid, block, lds, st, d, x, gh, gdst, pl.rounds); break;
-    case HG_METHOD_RBF:
-      hipLaunchKernelGGL((k_hist_bwd<T, HG_METHOD_RBF>), grid, block, lds, st, d, x, gh, gdst, pl.rounds); break;
-    default:
-      hipLaunchKernelGGL((k_hist_bwd<T, HG_METHOD_INVERSE_QUADRATIC>), grid, block, lds, st, d, x, gh, gdst, pl.rounds); break;
-  }
+  if (d.green) hipLaunchKernelGGL((k_hist_bwd<T, METHOD, true>), grid, block, lds, st, d, x, gout, hist, sums, gdst, pl.rounds);
+  else hipLaunchKernelGGL((k_hist_bwd<T, METHOD, false>), grid, block, lds, st, d, x, gout, hist, sums, gdst, pl.rounds);
   HG_LAUNCH_CHECK();
   return HG_OK;
+}
+
+template <int T>
+int launch_bwd_t(const DevParams &d, const Plan &pl, const float *x, const float *gout, const float *hist,
+                 const float *sums, float *gdst, hipStream_t st) {
+  switch (d.method) {
+    case HG_METHOD_THRESHOLDING: return launch_bwd_tm<T, HG_METHOD_THRESHOLDING>(d, pl, x, gout, hist, sums, gdst, st);
+    case HG_METHOD_RBF: return launch_bwd_tm<T, HG_METHOD_RBF>(d, pl, x, gout, hist, sums, gdst, st);
+    default: return launch_bwd_tm<T, HG_METHOD_INVERSE_QUADRATIC>(d, pl, x, gout, hist, sums, gdst, st);
+  }
 }
 
 }  // namespace
@@ -712,9 +825,6 @@ int hg_rgbuv_hist_bwd(const hg_hist_params *p, const float *x, const float *grad
   hipStream_t st = (hipStream_t)stream;
   const DevParams d = make_dev(p);
   float *gxs = (float *)workspace;
-  float *gh = (float *)((char *)workspace + pl.gxs_bytes);
-  hipLaunchKernelGGL(k_hist_bwd_prep, dim3(d.B), dim3(256), 0, st, grad_out, hist_out, sum_out, gh, d.h, pl.HP, d.green);
-  HG_LAUNCH_CHECK();
   const size_t gx_bytes = (size_t)d.B * d.C * d.H * d.W * sizeof(float);
   float *gdst = grad_x;
   if (d.mode != HG_RESIZE_NONE) {
@@ -724,7 +834,8 @@ int hg_rgbuv_hist_bwd(const hg_hist_params *p, const float *x, const float *grad
       if (e != hipSuccess) return (int)e;
     }
   }
-  int r = (pl.T == 1) ? launch_bwd_t<1>(d, pl, x, gh, gdst, st) : launch_bwd_t<2>(d, pl, x, gh, gdst, st);
+  int r = (pl.T == 1) ? launch_bwd_t<1>(d, pl, x, grad_out, hist_out, sum_out, gdst, st)
+                     : launch_bwd_t<2>(d, pl, x, grad_out, hist_out, sum_out, gdst, st);
   if (r) return r;
   if (d.mode == HG_RESIZE_BILINEAR) {
     const long long total = (long long)d.B * d.H * d.W;
