@@ -79,8 +79,10 @@ __device__ __forceinline__ void sample_rgb(const DevParams &P, const float *xb, 
   const int ys = n / P.Ws, xs = n - ys * P.Ws;
   if (P.mode == HG_RESIZE_BILINEAR) {
     // aten upsample_bilinear2d, align_corners=False: src = scale*(dst+0.5)-0.5, clamped at 0
-    float sy = fmaxf(P.rscale_h * ((float)ys + 0.5f) - 0.5f, 0.f);
-    float sx = fmaxf(P.rscale_w * ((float)xs + 0.5f) - 0.5f, 0.f);
+    // (mul, then sub, each rounded -- as aten's area_pixel_compute_source_index<float>; an fma here
+    //  moves lambda by up to 1 ulp(src) ~ 1.5e-5 and the interpolated value by ~5e-6)
+    float sy = fmaxf(__fsub_rn(__fmul_rn(P.rscale_h, (float)ys + 0.5f), 0.5f), 0.f);
+    float sx = fmaxf(__fsub_rn(__fmul_rn(P.rscale_w, (float)xs + 0.5f), 0.5f), 0.f);
     const int y0 = min((int)sy, P.H - 1), x0 = min((int)sx, P.W - 1);
     const float ly = clamp01(sy - (float)y0), lx = clamp01(sx - (float)x0);
     const int y1 = y0 + (y0 < P.H - 1 ? 1 : 0), x1 = x0 + (x0 < P.W - 1 ? 1 : 0);
@@ -92,7 +94,11 @@ __device__ __forceinline__ void sample_rgb(const DevParams &P, const float *xb, 
       const float *pc = xb + c * P.sc;
       const float p00 = clamp01(pc[o00]), p01 = clamp01(pc[o01]);
       const float p10 = clamp01(pc[o10]), p11 = clamp01(pc[o11]);
-      v[c] = (1.f - ly) * ((1.f - lx) * p00 + lx * p01) + ly * ((1.f - lx) * p10 + lx * p11);
+      // 4 combined weights, fma chain: the form that reproduces aten's CPU kernel bit-for-bit on
+      // ~90 % of pixels (the separable forms match ~60 %; differences are 1 ulp of the pixel value)
+      const float wx0 = 1.f - lx, wy0 = 1.f - ly;
+      v[c] = fmaf(__fmul_rn(ly, lx), p11, fmaf(__fmul_rn(ly, wx0), p10,
+                  fmaf(__fmul_rn(wy0, lx), p01, __fmul_rn(__fmul_rn(wy0, wx0), p00))));
     }
     r = v[0]; g = v[1]; b = v[2];
   } else {
@@ -338,6 +344,33 @@ __global__ __launch_bounds__(256) void k_hist_normalize(float *__restrict__ hist
 // zero-padded to BLK x BLK, the accumulation layout of the forward): 2 x 48 KB of L2 reads per
 // workgroup instead of a separate low-occupancy prep launch.
 
+// Chain rule from (dL/da, dL/db, dL/dc, dL/dIy) to the pixel and the store:
+//   dL_R = da+db, dL_G = -da+dc, dL_B = -db-dc,  dx_c = dL_c/(x_c+1e-6) + dIy x_c/Iy,
+// masked by the clamp of RGBuvHistBlock.py:76 when written straight to grad_x.
+__device__ __forceinline__ void store_pixel_grad(const DevParams &P, const float *xb, int b, int n, float r_,
+                                                 float g_, float b_, float iy, float da, float db, float dc,
+                                                 float dIy, float *gdst) {
+  const float dLr = da + db, dLg = dc - da, dLb = -db - dc;
+  float dr = dLr / (r_ + kEps), dg = dLg / (g_ + kEps), dbl = dLb / (b_ + kEps);
+  if (P.intensity) {
+    const float w = dIy / iy;
+    dr = fmaf(w, r_, dr); dg = fmaf(w, g_, dg); dbl = fmaf(w, b_, dbl);
+  }
+  if (P.mode == HG_RESIZE_NONE) {
+    const int ys = n / P.Ws, xs = n - ys * P.Ws;
+    const long long xo = ys * P.sh + xs * P.sw;
+    const float xr = xb[xo], xg = xb[xo + P.sc], xbv = xb[xo + 2 * P.sc];
+    float *gb = gdst + ((long long)b * P.C) * P.npix + n;
+    gb[0] = (xr >= 0.f && xr <= 1.f) ? dr : 0.f;
+    gb[P.npix] = (xg >= 0.f && xg <= 1.f) ? dg : 0.f;
+    gb[2LL * P.npix] = (xbv >= 0.f && xbv <= 1.f) ? dbl : 0.f;
+  } else {
+    // gradient w.r.t. the resized (already clamped) image: gxs[b][3][Hs*Ws]
+    float *gb = gdst + ((long long)b * 3) * P.npix + n;
+    gb[0] = dr; gb[P.npix] = dg; gb[2LL * P.npix] = dbl;
+  }
+}
+
 // bin permutation shared by the MFMA K index and the accumulator row index (see k_hist_bwd)
 __device__ __forceinline__ constexpr int beta0(int s) { return (s & 3) + 8 * ((s >> 2) & 3) + 32 * (s >> 4); }
 
@@ -529,31 +562,93 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
 
     const float da = iy * P.dk_scale * gsum[0], db = iy * P.dk_scale * gsum[1], dc = iy * P.dk_scale * gsum[2];
     const float dIy = P.intensity ? 0.5f * isum : 0.f;
-    const float dLr = da + db, dLg = dc - da, dLb = -db - dc;
-    float dr = dLr / (r_ + kEps), dg = dLg / (g_ + kEps), dbl = dLb / (b_ + kEps);
-    if (P.intensity) {
-      const float w = dIy / iy;
-      dr = fmaf(w, r_, dr); dg = fmaf(w, g_, dg); dbl = fmaf(w, b_, dbl);
-    }
-    if (valid && half == 0) {
-      if (P.mode == HG_RESIZE_NONE) {
-        // direct write to grad_x (B,C,H,W contiguous) with the clamp mask of RGBuvHistBlock.py:76
-        const int ys = n / P.Ws, xs = n - ys * P.Ws;
-        const long long xo = ys * P.sh + xs * P.sw;
-        const float xr = xb[xo], xg = xb[xo + P.sc], xbv = xb[xo + 2 * P.sc];
-        float *gb = gdst + ((long long)b * P.C) * P.npix + n;
-        gb[0] = (xr >= 0.f && xr <= 1.f) ? dr : 0.f;
-        gb[P.npix] = (xg >= 0.f && xg <= 1.f) ? dg : 0.f;
-        gb[2LL * P.npix] = (xbv >= 0.f && xbv <= 1.f) ? dbl : 0.f;
-      } else {
-        // gradient w.r.t. the resized (already clamped) image: gxs[b][3][Hs*Ws]
-        float *gb = gdst + ((long long)b * 3) * P.npix + n;
-        gb[0] = dr; gb[P.npix] = dg; gb[2LL * P.npix] = dbl;
-      }
-    }
+    if (valid && half == 0) store_pixel_grad(P, xb, b, n, r_, g_, b_, iy, da, db, dc, dIy, gdst);
     if (valid && half == 1 && P.mode == HG_RESIZE_NONE) {
       for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic backward (any h, any hist_boundary): the reference's plane structure taken literally,
+// one pixel per lane, fp64 kernel evaluation, fp32 mat-vecs against Ghat held in global/L2 (every
+// lane reads the same Ghat element -> one broadcast load).  Used where the MFMA kernel does not
+// apply (h > 64 or an asymmetric boundary); ~10x slower per pixel but exact in structure.
+__global__ __launch_bounds__(256) void k_hist_ghat(const float *__restrict__ gout, const float *__restrict__ hist,
+                                                   const float *__restrict__ sums, float *__restrict__ gh, int n) {
+  __shared__ float sm4[4];
+  const int b = blockIdx.x;
+  const float *g = gout + (long long)b * n, *o = hist + (long long)b * n;
+  float d = 0.f;
+  for (int e = threadIdx.x; e < n; e += 256) d = fmaf(g[e], o[e], d);
+  d = hg_block_sum_256(d, sm4);
+  const float inv = 1.f / sums[b];
+  for (int e = threadIdx.x; e < n; e += 256) gh[(long long)b * n + e] = (g[e] - d) * inv;
+}
+
+template <int METHOD>
+__device__ __forceinline__ void kern_eval_d(const DevParams &P, float u, int i, float &k, float &dk) {
+  const double d = (double)u - bin_center(P, i);
+  if constexpr (METHOD == HG_METHOD_THRESHOLDING) {
+    k = (fabs(d) <= P.half_eps) ? 1.f : 0.f; dk = 0.f;
+  } else {
+    const double t = d * P.inv_sigma_x;
+    if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) {
+      const double kd = 1.0 / (1.0 + t * t);
+      k = (float)kd; dk = (float)(-2.0 * t * kd * kd * P.inv_sigma_x);
+    } else {
+      const double kd = exp(-t * t);
+      k = (float)kd; dk = (float)(-2.0 * t * kd * P.inv_sigma_x);
+    }
+  }
+}
+
+template <int METHOD>
+__global__ __launch_bounds__(64) void k_hist_bwd_generic(const DevParams P, const float *__restrict__ x,
+                                                         const float *__restrict__ gh, float *__restrict__ gdst) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *kbuf = reinterpret_cast<float *>(smem);  // [h][64]
+  const int lane = threadIdx.x, b = blockIdx.y, h = P.h;
+  const int n = blockIdx.x * 64 + lane;
+  const bool valid = n < P.npix;
+  const float *xb = x + (long long)b * P.sb;
+  float r_ = 0.f, g_ = 0.f, b_ = 0.f;
+  if (valid) sample_rgb(P, xb, n, r_, g_, b_);
+  float a, bb, c, iy;
+  project(P, r_, g_, b_, a, bb, c, iy);
+  // plane p: (u, v) = (su*U, sv*V) with U,V in {a,b,c}  (RGBuvHistBlock.py:112-115,150-153,190-193)
+  const float uvals[3] = {a, -a, -bb}, vvals[3] = {bb, c, -c};
+  float gu[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f}, isum = 0.f;
+  for (int p = 0; p < 3; ++p) {
+    if (P.green && p != 1) continue;
+    const float *G = gh + ((long long)b * P.P + (P.green ? 0 : p)) * h * h;
+    const float u = uvals[p], v = vvals[p];
+    // pass 1: T_i = sum_j G[i][j] kv_j ;  g_u += k'u_i T_i ;  dIy += ku_i T_i
+    for (int j = 0; j < h; ++j) { float k, dk; kern_eval_d<METHOD>(P, v, j, k, dk); kbuf[j * 64 + lane] = k; }
+    for (int i = 0; i < h; ++i) {
+      float T = 0.f;
+      const float *Gi = G + (long long)i * h;
+      for (int j = 0; j < h; ++j) T = fmaf(Gi[j], kbuf[j * 64 + lane], T);
+      float k, dk; kern_eval_d<METHOD>(P, u, i, k, dk);
+      gu[p] = fmaf(dk, T, gu[p]);
+      isum = fmaf(k, T, isum);
+    }
+    // pass 2: Sx_j = sum_i G[i][j] ku_i ;  g_v += k'v_j Sx_j
+    for (int i = 0; i < h; ++i) { float k, dk; kern_eval_d<METHOD>(P, u, i, k, dk); kbuf[i * 64 + lane] = k; }
+    for (int j = 0; j < h; ++j) {
+      float Sx = 0.f;
+      for (int i = 0; i < h; ++i) Sx = fmaf(G[(long long)i * h + j], kbuf[i * 64 + lane], Sx);
+      float k, dk; kern_eval_d<METHOD>(P, v, j, k, dk);
+      gv[p] = fmaf(dk, Sx, gv[p]);
+    }
+  }
+  // u0 = a, v0 = b, u1 = -a, v1 = c, u2 = -b, v2 = -c
+  const float da = iy * (gu[0] - gu[1]), db = iy * (gv[0] - gu[2]), dc = iy * (gv[1] - gv[2]);
+  const float dIy = P.intensity ? isum : 0.f;
+  if (valid) {
+    store_pixel_grad(P, xb, b, n, r_, g_, b_, iy, da, db, dc, dIy, gdst);
+    if (P.mode == HG_RESIZE_NONE)
+      for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
   }
 }
 
@@ -575,7 +670,7 @@ __global__ __launch_bounds__(256) void k_bilinear_adjoint(const DevParams P, con
   float acc[3] = {0.f, 0.f, 0.f};
   const float *gb = gxs + (long long)b * 3 * P.npix;
   for (int Y = Ylo; Y <= Yhi; ++Y) {
-    const float sy = fmaxf(P.rscale_h * ((float)Y + 0.5f) - 0.5f, 0.f);
+    const float sy = fmaxf(__fsub_rn(__fmul_rn(P.rscale_h, (float)Y + 0.5f), 0.5f), 0.f);
     const int y0 = min((int)sy, P.H - 1);
     const float ly = clamp01(sy - (float)y0);
     const int y1 = y0 + (y0 < P.H - 1 ? 1 : 0);
@@ -584,7 +679,7 @@ __global__ __launch_bounds__(256) void k_bilinear_adjoint(const DevParams P, con
     if (y1 == yy) wy += ly;
     if (wy == 0.f) continue;
     for (int X = Xlo; X <= Xhi; ++X) {
-      const float sx = fmaxf(P.rscale_w * ((float)X + 0.5f) - 0.5f, 0.f);
+      const float sx = fmaxf(__fsub_rn(__fmul_rn(P.rscale_w, (float)X + 0.5f), 0.5f), 0.f);
       const int x0 = min((int)sx, P.W - 1);
       const float lx = clamp01(sx - (float)x0);
       const int x1 = x0 + (x0 < P.W - 1 ? 1 : 0);
@@ -687,7 +782,8 @@ Plan make_plan(const hg_hist_params *p) {
   Sb = (rounds_total + 4 * rpw - 1) / (4 * rpw);
   pl.S_bwd = (int)Sb;
   pl.rounds = (int)rpw;
-  pl.gh_bytes = 256;  // (unused; keeps the workspace pointer non-empty)
+  // generic backward only (h > 64 or asymmetric boundary): Ghat in natural layout
+  pl.gh_bytes = ((p->lo != -p->hi) || pl.nbd != 1) ? ((size_t)p->B * n_per_img * sizeof(float) + 255) / 256 * 256 : 256;
   pl.gxs_bytes = (p->resize_mode == HG_RESIZE_NONE) ? 0 : ((size_t)p->B * 3 * npix * sizeof(float) + 255) / 256 * 256;
   return pl;
 }
@@ -821,7 +917,7 @@ int hg_rgbuv_hist_bwd(const hg_hist_params *p, const float *x, const float *grad
   const Plan pl = make_plan(p);
   if (workspace_bytes < pl.gxs_bytes + pl.gh_bytes) return HG_EWORKSPACE;
   const bool sym = (p->lo == -p->hi);
-  if (!sym || pl.nbd != 1) return HG_EUNSUPPORTED;
+  const bool generic = !sym || pl.nbd != 1;
   hipStream_t st = (hipStream_t)stream;
   const DevParams d = make_dev(p);
   float *gxs = (float *)workspace;
@@ -834,9 +930,28 @@ int hg_rgbuv_hist_bwd(const hg_hist_params *p, const float *x, const float *grad
       if (e != hipSuccess) return (int)e;
     }
   }
-  int r = (pl.T == 1) ? launch_bwd_t<1>(d, pl, x, grad_out, hist_out, sum_out, gdst, st)
-                     : launch_bwd_t<2>(d, pl, x, grad_out, hist_out, sum_out, gdst, st);
-  if (r) return r;
+  if (!generic) {
+    int r = (pl.T == 1) ? launch_bwd_t<1>(d, pl, x, grad_out, hist_out, sum_out, gdst, st)
+                        : launch_bwd_t<2>(d, pl, x, grad_out, hist_out, sum_out, gdst, st);
+    if (r) return r;
+  } else {
+    float *gh = (float *)((char *)workspace + pl.gxs_bytes);
+    const int n_per_img = d.P * d.h * d.h;
+    hipLaunchKernelGGL(k_hist_ghat, dim3(d.B), dim3(256), 0, st, grad_out, hist_out, sum_out, gh, n_per_img);
+    HG_LAUNCH_CHECK();
+    const size_t lds = (size_t)d.h * 64 * sizeof(float);
+    if (lds > 160 * 1024) return HG_EUNSUPPORTED;  // h > 640
+    const dim3 grid((d.npix + 63) / 64, d.B), block(64);
+    switch (d.method) {
+      case HG_METHOD_THRESHOLDING:
+        hipLaunchKernelGGL((k_hist_bwd_generic<HG_METHOD_THRESHOLDING>), grid, block, lds, st, d, x, gh, gdst); break;
+      case HG_METHOD_RBF:
+        hipLaunchKernelGGL((k_hist_bwd_generic<HG_METHOD_RBF>), grid, block, lds, st, d, x, gh, gdst); break;
+      default:
+        hipLaunchKernelGGL((k_hist_bwd_generic<HG_METHOD_INVERSE_QUADRATIC>), grid, block, lds, st, d, x, gh, gdst); break;
+    }
+    HG_LAUNCH_CHECK();
+  }
   if (d.mode == HG_RESIZE_BILINEAR) {
     const long long total = (long long)d.B * d.H * d.W;
     hipLaunchKernelGGL(k_bilinear_adjoint, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, x, gxs, grad_x);

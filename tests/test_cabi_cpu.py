@@ -1,0 +1,77 @@
+"""CPU-side checks of the C ABI: the library builds/loads, exports every symbol include/hg_hist.h
+declares, and its host-only entry points (argument validation, workspace sizing) behave.
+No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def L():
+    from histogan_amd import build
+    build.build()
+    import histogan_amd._lib as L
+    return L
+
+
+def _declared_symbols():
+    syms = set()
+    for fn in os.listdir(os.path.join(ROOT, 'include')):
+        txt = open(os.path.join(ROOT, 'include', fn)).read()
+        txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+        syms |= set(re.findall(r'\b(hg_[a-z0-9_]+)\s*\(', txt))
+    return syms
+
+
+def test_exports_match_header(L):
+    declared = _declared_symbols()
+    assert declared, 'no declarations parsed'
+    for name in declared:
+        assert hasattr(L.lib, name), f'{name} declared in include/ but not exported'
+    assert set(L.EXPORTS) <= declared
+
+
+def test_version_and_error_strings(L):
+    assert L.lib.hg_version() >= 100
+    assert b'kernel method' in L.lib.hg_error_string(-2)
+    assert b'resizing method' in L.lib.hg_error_string(-3)
+
+
+def _params(L, **kw):
+    p = L.HgHistParams()
+    p.B, p.C, p.H, p.W = 2, 3, 16, 16
+    p.stride_b, p.stride_c, p.stride_h, p.stride_w = 3 * 256, 256, 16, 1
+    p.Hs, p.Ws, p.resize_mode = 16, 16, 0
+    p.h, p.lo, p.hi, p.method, p.sigma = 64, -3.0, 3.0, 2, 0.02
+    p.intensity_scale, p.green_only = 1, 0
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def test_workspace_query_and_validation(L):
+    f, b = ctypes.c_size_t(), ctypes.c_size_t()
+    assert L.lib.hg_rgbuv_hist_workspace_bytes(ctypes.byref(_params(L)), ctypes.byref(f), ctypes.byref(b)) == 0
+    assert f.value >= 2 * 3 * 64 * 64 * 4 and b.value > 0
+    bad = [dict(method=7), dict(resize_mode=9), dict(h=0), dict(C=2), dict(sigma=0.0), dict(Hs=8)]
+    codes = [L.lib.hg_rgbuv_hist_workspace_bytes(ctypes.byref(_params(L, **kw)), ctypes.byref(f), ctypes.byref(b))
+             for kw in bad]
+    assert codes[0] == -2 and codes[1] == -3 and all(c < 0 for c in codes)
+
+
+def test_null_pointers_rejected_before_any_launch(L):
+    p = _params(L)
+    assert L.lib.hg_rgbuv_hist_fwd(ctypes.byref(p), None, None, None, None, 0, None) == -1
+    assert L.lib.hg_rgbuv_hist_bwd(ctypes.byref(p), None, None, None, None, None, None, 0, None) == -1
+    assert L.lib.hg_hellinger_fwd_bwd(None, None, 10, 1, 1.0, None, None, None, 0, None) == -1
+
+
+def test_cpu_tensor_is_refused_loudly(L):
+    import torch
+    from histogram_classes.RGBuvHistBlock import RGBuvHistBlock
+    with pytest.raises(RuntimeError):
+        RGBuvHistBlock(device='cpu')(torch.rand(1, 3, 8, 8))
