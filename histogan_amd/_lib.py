@@ -56,6 +56,19 @@ def _load():
     lib.hg_hellinger_workspace_bytes.argtypes = [i64]
     lib.hg_hellinger_fwd_bwd.restype = ctypes.c_int
     lib.hg_hellinger_fwd_bwd.argtypes = [vp, vp, i64, i32, f32, vp, vp, vp, sz, vp]
+    # include/hg_nets.h
+    lib.hg_modulate_fwd.restype = ctypes.c_int
+    lib.hg_modulate_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.hg_modulate_bwd.restype = ctypes.c_int
+    lib.hg_modulate_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.hg_demod_noise_lrelu_fwd.restype = ctypes.c_int
+    lib.hg_demod_noise_lrelu_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.hg_demod_noise_lrelu_bwd.restype = ctypes.c_int
+    lib.hg_demod_noise_lrelu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.hg_diffgrad_step.restype = ctypes.c_int
+    lib.hg_diffgrad_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]
+    lib.hg_ema_update.restype = ctypes.c_int
+    lib.hg_ema_update.argtypes = [vp, vp, i64, f32, vp]
     return lib
 
 
@@ -63,7 +76,9 @@ lib = _load()
 
 # every symbol include/hg_hist.h declares
 EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_fwd',
-           'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd')
+           'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd',
+           'hg_modulate_fwd', 'hg_modulate_bwd', 'hg_demod_noise_lrelu_fwd', 'hg_demod_noise_lrelu_bwd',
+           'hg_diffgrad_step', 'hg_ema_update')
 
 
 class HgError(RuntimeError):

@@ -1,0 +1,72 @@
+"""Data parallelism for the HistoGAN train step: one process per GPU, torch.distributed
+(backend 'nccl' == RCCL over xGMI on ROCm; 'gloo' for the CPU tests).
+
+The reference is single-GPU (histoGAN.py:242,268); these semantics are new:
+* parameters replicated, broadcast from rank 0 at init / after load;
+* each rank draws its own latents / noise / data shard; global batch = sum of rank batches;
+* gradients averaged with ONE large all-reduce per optimizer over its flat gradient buffer
+  (399 MB for G+S+H, 364 MB for D at 256^2/cap16) -- on the fully connected 8-GPU xGMI mesh a few
+  large collectives use all 7 links per GPU, where many small per-tensor ones would be latency-bound;
+* the D-gradient all-reduce is launched asynchronously right after the D backward and overlaps the
+  generator forward of the G phase (which does not touch D); it is waited for before D_opt.step();
+* scalar state that steers control flow (NaN flag, pl_mean) is all-reduced so ranks never diverge.
+"""
+import torch
+import torch.distributed as dist
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def world_size():
+    return dist.get_world_size() if is_dist() else 1
+
+
+def rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def broadcast_flat(flat, src=0):
+    if is_dist():
+        dist.broadcast(flat.data, src)
+
+
+class GradAllReduce:
+    """Averaging all-reduce of a flat gradient buffer, optionally asynchronous."""
+
+    def __init__(self, flat, chunks=1):
+        self.flat = flat
+        self.chunks = max(1, int(chunks))
+        self._work = []
+
+    def start(self):
+        if not is_dist():
+            return
+        g = self.flat.grad
+        g.mul_(1.0 / world_size())
+        for c in g.chunk(self.chunks):
+            self._work.append(dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self):
+        for w in self._work:
+            w.wait()
+        self._work = []
+
+    def __call__(self):
+        self.start()
+        self.finish()
+
+
+def all_reduce_scalar(value, op='mean', device=None):
+    """All-reduce a python float ('mean' | 'max' | 'sum'); identity when not distributed."""
+    if not is_dist():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if op == 'max':
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if op == 'mean':
+            t /= world_size()
+    return float(t.item())

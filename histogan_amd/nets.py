@@ -1,0 +1,240 @@
+"""HistoGAN networks on the MI355X kernels: same classes, constructor arguments, forward signatures and
+state_dict key names as histoGAN/histoGAN.py of the reference (so its checkpoints load), different
+execution plan:
+
+* Conv2DMod (reference :404-440) runs in activation-modulation form
+      out = d[b,o] * conv(up?(x) * (s+1), W),   d = rsqrt(((s+1)^2) @ sum_k W^2 + 1e-8)
+  -- prologue/epilogue are the fused HIP kernels of histogan_amd/csrc/hg_nets.hip, the dense contraction
+  uses the SHARED weight (no B x O x I x k x k per-sample weights, no grouped conv).
+* GeneratorBlock (reference :443-502) fuses the bilinear x2 upsample into conv1's prologue and the
+  noise add + LeakyReLU(0.2) (+ demodulation) into each conv's epilogue.
+* Discriminator / vectorizers are plain PyTorch-ROCm modules (MIOpen / rocBLAS): the discriminator must
+  stay twice differentiable for the gradient penalty (reference :156-163).
+"""
+from math import log2
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+EPS = 1e-8  # histoGAN/histoGAN.py:53
+
+
+def leaky_relu(p=0.2):
+    return nn.LeakyReLU(p, inplace=True)
+
+
+class Flatten(nn.Module):
+    def forward(self, x):
+        return x.reshape(x.shape[0], -1)
+
+
+def _noise_t(inoise):
+    """(B,S,S,1) noise image -> (B,S,S) transposed copy, cached on the tensor for the G forward."""
+    nzt = getattr(inoise, '_hg_nzt', None)
+    if nzt is None:
+        nzt = inoise[..., 0].transpose(1, 2).contiguous()
+        try:
+            inoise._hg_nzt = nzt
+        except Exception:
+            pass
+    return nzt
+
+
+class Conv2DMod(nn.Module):
+    def __init__(self, in_chan, out_chan, kernel, demod=True, stride=1, dilation=1, **kwargs):
+        super().__init__()
+        self.filters = out_chan
+        self.demod = demod
+        self.kernel = kernel
+        self.stride = stride
+        self.dilation = dilation
+        self.weight = nn.Parameter(torch.randn((out_chan, in_chan, kernel, kernel)))
+        nn.init.kaiming_normal_(self.weight, a=0, mode='fan_in', nonlinearity='leaky_relu')
+
+    def _get_same_padding(self, size, kernel, dilation, stride):
+        return ((size - 1) * (stride - 1) + dilation * (kernel - 1)) // 2
+
+    def demod_coeff(self, y):
+        """d[b,o] = rsqrt(sum_{i,k} (W[o,i,k] (y[b,i]+1))^2 + EPS)   (reference :427-429)."""
+        wsq = self.weight.pow(2).sum(dim=(2, 3))
+        return torch.rsqrt(torch.mm((y + 1).pow(2), wsq.t()) + EPS)
+
+    def contract(self, x, y, upsample=False):
+        """conv(up?(x) * (y+1), W): the dense part, shared weights."""
+        if self.stride != 1:
+            raise NotImplementedError('Conv2DMod: stride != 1 is not used by HistoGAN and not implemented')
+        xm = ops.modulate(x, y, upsample)
+        pad = self._get_same_padding(xm.shape[2], self.kernel, self.dilation, self.stride)
+        return F.conv2d(xm, self.weight, padding=pad, dilation=self.dilation)
+
+    def forward(self, x, y):
+        c = self.contract(x, y)
+        if self.demod:
+            c = c * self.demod_coeff(y)[:, :, None, None]
+        return c
+
+
+class RGBBlock(nn.Module):
+    def __init__(self, latent_dim, input_channel, upsample, rgba=False):
+        super().__init__()
+        self.input_channel = input_channel
+        self.to_style = nn.Linear(latent_dim, input_channel)
+        out_filters = 3 if not rgba else 4
+        self.conv = Conv2DMod(input_channel, out_filters, 1, demod=False)
+        # kept for state_dict/attribute parity; the HIP upsample kernel is used in forward
+        self.upsample = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) if upsample else None
+
+    def forward(self, x, prev_rgb, istyle):
+        return self.forward_(x, prev_rgb, self.to_style(istyle))
+
+    def forward_(self, x, prev_rgb, style):
+        x = self.conv(x, style)
+        if prev_rgb is not None:
+            x = x + prev_rgb
+        if self.upsample is not None:
+            x = ops.upsample2x(x)
+        return x
+
+
+class GeneratorBlock(nn.Module):
+    def __init__(self, latent_dim, input_channels, filters, upsample=True, upsample_rgb=True, rgba=False):
+        super().__init__()
+        self.upsample = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) if upsample else None
+        self.to_style1 = nn.Linear(latent_dim, input_channels)
+        self.to_noise1 = nn.Linear(1, filters)
+        self.conv1 = Conv2DMod(input_channels, filters, 3)
+        self.to_style2 = nn.Linear(latent_dim, filters)
+        self.to_noise2 = nn.Linear(1, filters)
+        self.conv2 = Conv2DMod(filters, filters, 3)
+        self.activation = leaky_relu()
+        self.to_rgb = RGBBlock(latent_dim, filters, upsample_rgb, rgba)
+
+    def _stage(self, conv, x, style, nzt, to_noise, upsample):
+        c = conv.contract(x, style, upsample)
+        d = conv.demod_coeff(style) if conv.demod else None
+        return ops.demod_noise_lrelu(c, d, nzt, to_noise.weight, to_noise.bias)
+
+    def forward(self, x, prev_rgb, istyle, inoise, latent=None):
+        return self.forward_(x, prev_rgb, self.to_style1(istyle), self.to_style2(istyle),
+                             self.to_rgb.to_style(istyle), inoise=inoise, latent=latent)
+
+    def forward_(self, x, prev_rgb, style1, style2, to_rgb_style, inoise=None, noise1=None, noise2=None,
+                 latent=None):
+        if noise1 is not None and noise2 is not None:
+            # explicit per-pixel noise tensors (projection scripts): unfused path, same maths
+            if self.upsample is not None:
+                x = ops.upsample2x(x)
+            x = F.leaky_relu(self.conv1(x, style1) + noise1, 0.2)
+            if latent is not None:
+                x = x + latent
+            x = F.leaky_relu(self.conv2(x, style2) + noise2, 0.2)
+            return x, self.to_rgb.forward_(x, prev_rgb, to_rgb_style)
+        if inoise is None:
+            raise Exception('No noise is given')
+        nzt = _noise_t(inoise)
+        x = self._stage(self.conv1, x, style1, nzt, self.to_noise1, self.upsample is not None)
+        if latent is not None:
+            x = x + latent
+        x = self._stage(self.conv2, x, style2, nzt, self.to_noise2, False)
+        return x, self.to_rgb.forward_(x, prev_rgb, to_rgb_style)
+
+
+class Generator(nn.Module):
+    def __init__(self, image_size, latent_dim, network_capacity=16, transparent=False):
+        super().__init__()
+        self.image_size = image_size
+        self.latent_dim = latent_dim
+        self.num_layers = int(log2(image_size) - 1)
+        init_channels = 4 * network_capacity
+        self.initial_block = nn.Parameter(torch.randn((init_channels, 4, 4)))
+        filters = [init_channels] + [network_capacity * (2 ** (i + 1)) for i in range(self.num_layers)][::-1]
+        self.blocks = nn.ModuleList([])
+        for ind, (in_chan, out_chan) in enumerate(zip(filters[0:-1], filters[1:])):
+            self.blocks.append(GeneratorBlock(latent_dim, in_chan, out_chan, upsample=ind != 0,
+                                              upsample_rgb=ind != (self.num_layers - 1), rgba=transparent))
+
+    def forward(self, styles, hists, input_noise):
+        batch_size = styles.shape[0]
+        x = self.initial_block.expand(batch_size, -1, -1, -1)
+        styles = torch.cat((styles.transpose(0, 1), hists.transpose(0, 1)), dim=0)
+        _noise_t(input_noise)
+        rgb = None
+        for style, block in zip(styles, self.blocks):
+            x, rgb = block(x, rgb, style, input_noise)
+        return rgb
+
+
+class HistVectorizer(nn.Module):
+    def __init__(self, insize, emb, depth):
+        super().__init__()
+        self.flatten = Flatten()
+        fc_layers = []
+        for i in range(depth):
+            if i == 0:
+                fc_layers.extend([nn.Linear(insize * insize * 3, emb * 2), leaky_relu()])
+            elif i == 1:
+                fc_layers.extend([nn.Linear(emb * 2, emb), leaky_relu()])
+            else:
+                fc_layers.extend([nn.Linear(emb, emb), leaky_relu()])
+        self.fcs = nn.Sequential(*fc_layers)
+
+    def forward(self, x):
+        return self.fcs(self.flatten(x))
+
+
+class StyleVectorizer(nn.Module):
+    def __init__(self, emb, depth):
+        super().__init__()
+        layers = []
+        for i in range(depth):
+            layers.extend([nn.Linear(emb, emb), leaky_relu()])
+        self.net = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class DiscriminatorBlock(nn.Module):
+    def __init__(self, input_channels, filters, downsample=True):
+        super().__init__()
+        self.conv_res = nn.Conv2d(input_channels, filters, 1)
+        self.net = nn.Sequential(nn.Conv2d(input_channels, filters, 3, padding=1), leaky_relu(),
+                                 nn.Conv2d(filters, filters, 3, padding=1), leaky_relu())
+        self.downsample = nn.Conv2d(filters, filters, 3, padding=1, stride=2) if downsample else None
+
+    def forward(self, x):
+        res = self.conv_res(x)
+        x = self.net(x)
+        x = x + res
+        if self.downsample is not None:
+            x = self.downsample(x)
+        return x
+
+
+class Discriminator(nn.Module):
+    def __init__(self, image_size, network_capacity=16, fq_layers=[], fq_dict_size=256, attn_layers=[],
+                 transparent=False):
+        super().__init__()
+        if list(fq_layers) or list(attn_layers):
+            raise NotImplementedError('fq_layers / attn_layers need vector_quantize_pytorch / '
+                                      'linear_attention_transformer (third-party, absent): not implemented')
+        num_layers = int(log2(image_size) - 1)
+        num_init_filters = 3 if not transparent else 4
+        filters = [num_init_filters] + [network_capacity * (2 ** i) for i in range(num_layers + 1)]
+        chan_in_out = list(zip(filters[0:-1], filters[1:]))
+        self.blocks = nn.ModuleList([DiscriminatorBlock(i, o, downsample=ind != (len(chan_in_out) - 1))
+                                     for ind, (i, o) in enumerate(chan_in_out)])
+        self.attn_blocks = nn.ModuleList([None for _ in chan_in_out])
+        self.quantize_blocks = nn.ModuleList([None for _ in chan_in_out])
+        self.flatten = Flatten()
+        self.to_logit = nn.Linear(2 * 2 * filters[-1], 1)
+
+    def forward(self, x):
+        quantize_loss = torch.zeros(1).to(x)
+        for block in self.blocks:
+            x = block(x)
+        x = self.to_logit(self.flatten(x))
+        return x.squeeze(), quantize_loss

@@ -1,0 +1,91 @@
+"""Flat parameter storage, fused DiffGrad and fused EMA (hg_diffgrad_step / hg_ema_update).
+
+MI355X-first layout: every optimizer owns ONE contiguous fp32 parameter buffer and ONE contiguous
+gradient buffer (parameters / .grad are views into them).  One kernel launch updates all parameters,
+one (or a few large) collectives reduce all gradients, EMA is one launch -- instead of ~12 aten
+launches per parameter tensor (reference: torch_optimizer.DiffGrad over ~150 tensors, and the
+per-tensor EMA loop of histoGAN/histoGAN.py:698-707).
+"""
+import ctypes
+
+import torch
+
+from ._lib import check, lib
+
+
+def _st(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class FlatParams:
+    """Re-home `params` (already on their final device) into one flat buffer; optionally with grads."""
+
+    def __init__(self, params, with_grad=True):
+        self.params = []
+        seen = set()
+        for p in params:
+            if id(p) not in seen:
+                seen.add(id(p))
+                self.params.append(p)
+        if not self.params:
+            raise ValueError('no parameters')
+        dev = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.data = torch.empty(self.numel, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.numel, dtype=torch.float32, device=dev) if with_grad else None
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            view = self.data[off:off + n].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            if with_grad:
+                p.grad = self.grad[off:off + n].view(p.shape)
+            off += n
+
+    def zero_grad(self):
+        # keep the views alive: autograd accumulates in place into an existing .grad
+        self.grad.zero_()
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + n].view(p.shape)
+            off += n
+
+
+class DiffGrad:
+    """DiffGrad (Dubey et al.; torch_optimizer.DiffGrad as used at histoGAN/histoGAN.py:670-671) over a
+    FlatParams: p -= lr*sqrt(1-b2^t)/(1-b1^t) * (m * dfc) / (sqrt(v)+eps), dfc = sigmoid(|g_prev - g|)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.flat = params if isinstance(params, FlatParams) else FlatParams(params)
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        z = lambda: torch.zeros_like(self.flat.data)
+        self.exp_avg, self.exp_avg_sq, self.previous_grad = z(), z(), z()
+        self.param_groups = [{'params': self.flat.params, 'lr': lr, 'betas': betas, 'eps': eps}]
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.zero_grad()
+
+    def step(self):
+        f = self.flat
+        if not f.data.is_cuda:
+            raise RuntimeError('DiffGrad: parameters are not on a GPU; no CPU implementation')
+        self.step_count += 1
+        lr = self.param_groups[0]['lr']
+        with torch.cuda.device(f.data.device):
+            check(lib.hg_diffgrad_step(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), self.previous_grad.data_ptr(), f.numel,
+                                       float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                       self.step_count, _st(f.data)), 'hg_diffgrad_step')
+
+
+def ema_update(ma_flat, cur_flat, beta):
+    """ma = beta*ma + (1-beta)*cur over two FlatParams with identical layout (HistoGAN.EMA)."""
+    if ma_flat.numel != cur_flat.numel:
+        raise ValueError('EMA buffers differ in size')
+    with torch.cuda.device(ma_flat.data.device):
+        check(lib.hg_ema_update(ma_flat.data.data_ptr(), cur_flat.data.data_ptr(), ma_flat.numel, float(beta),
+                                _st(ma_flat.data)), 'hg_ema_update')

@@ -1,0 +1,546 @@
+"""HistoGAN container + Trainer on the MI355X path.
+
+API mirror of histoGAN/histoGAN.py (reference): `HistoGAN` (:634-715) and `Trainer` (:718-1139) keep
+their constructor arguments, attribute names (`GAN.{S,H,G,D,SE,HE,GE,G_opt,D_opt}`, `steps`, ...),
+method names and the checkpoint format (`torch.save(GAN.state_dict())`, `.config.json`).
+`Trainer.train(alpha)` performs the same D step + G step (hinge loss, gradient penalty every 4th step,
+Hellinger histogram loss, image-space path-length regulariser every 32nd step, DiffGrad, EMA schedule,
+NaN recovery) -- restructured for the hardware:
+
+* one process per GPU; gradients averaged over ranks (histogan_amd/ddp.py); the D-gradient all-reduce
+  overlaps the generator forward of the G phase;
+* flat parameter/gradient buffers, fused DiffGrad / EMA kernels (histogan_amd/optim.py);
+* the D phase runs the generator under no_grad (the reference builds and discards that graph, :904-910);
+* ONE device->host read-back per step (losses + NaN flag together) instead of >= 7 `.item()` syncs;
+* latents / noise drawn on the device (rng='device'); rng='reference' reproduces the reference's CPU
+  draws (`torch.randn(...).cuda()`, :166-189) for parity tests.
+"""
+import json
+from math import floor, log2
+from pathlib import Path
+from random import random
+from shutil import rmtree
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.autograd import grad as torch_grad
+
+from . import ddp
+from .hist import hellinger_loss
+from .nets import Discriminator, Generator, HistVectorizer, StyleVectorizer
+from .optim import DiffGrad, FlatParams, ema_update
+
+EPS = 1e-8
+EXTS = ['jpg', 'png']
+
+
+class NanException(Exception):
+    pass
+
+
+class EMA():
+    def __init__(self, beta):
+        super().__init__()
+        self.beta = beta
+
+    def update_average(self, old, new):
+        if old is None:
+            return new
+        return old * self.beta + (1 - self.beta) * new
+
+
+def default(value, d):
+    return d if value is None else value
+
+
+def cast_list(el):
+    return el if isinstance(el, list) else [el]
+
+
+def is_empty(t):
+    if isinstance(t, torch.Tensor):
+        return t.nelement() == 0
+    return t is None
+
+
+def set_requires_grad(model, bool):
+    for p in model.parameters():
+        p.requires_grad = bool
+
+
+def gradient_penalty(images, output, weight=10):
+    """10 * mean((||grad_x D(x)||_2 - 1)^2) on real images, double-differentiable (reference :156-163)."""
+    batch_size = images.shape[0]
+    gradients = torch_grad(outputs=output, inputs=images, grad_outputs=torch.ones_like(output),
+                           create_graph=True, retain_graph=True, only_inputs=True)[0]
+    gradients = gradients.reshape(batch_size, -1)
+    return weight * ((gradients.norm(2, dim=1) - 1) ** 2).mean()
+
+
+class _Rng:
+    """Latent / noise draws (reference :166-189).  'device': on the GPU; 'reference': CPU draw + copy."""
+
+    def __init__(self, device, mode='device'):
+        self.device, self.mode = device, mode
+
+    def noise(self, n, latent_dim):
+        if self.mode == 'reference':
+            return torch.randn(n, latent_dim).to(self.device)
+        return torch.randn(n, latent_dim, device=self.device)
+
+    def noise_list(self, n, layers, latent_dim):
+        return [(self.noise(n, latent_dim), layers)]
+
+    def mixed_list(self, n, layers, latent_dim):
+        tt = int(torch.rand(()).numpy() * layers)
+        return self.noise_list(n, tt, latent_dim) + self.noise_list(n, layers - tt, latent_dim)
+
+    def image_noise(self, n, im_size):
+        if self.mode == 'reference':
+            return torch.FloatTensor(n, im_size, im_size, 1).uniform_(0.0, 1.0).to(self.device)
+        return torch.rand(n, im_size, im_size, 1, device=self.device)
+
+    def randn_like(self, t):
+        if self.mode == 'reference':
+            return torch.randn(t.shape).to(self.device)
+        return torch.randn_like(t)
+
+
+def latent_to_w(style_vectorizer, latent_descr):
+    return [(style_vectorizer(z), num_layers) for z, num_layers in latent_descr]
+
+
+def styles_def_to_tensor(styles_def):
+    return torch.cat([t[:, None, :].expand(-1, n, -1) for t, n in styles_def], dim=1)
+
+
+def evaluate_in_chunks(max_batch_size, model, *args):
+    split_args = list(zip(*list(map(lambda x: x.split(max_batch_size, dim=0), args))))
+    chunked_outputs = [model(*i) for i in split_args]
+    if len(chunked_outputs) == 1:
+        return chunked_outputs[0]
+    return torch.cat(chunked_outputs, dim=0)
+
+
+class HistoGAN(nn.Module):
+    def __init__(self, image_size, latent_dim=512, style_depth=8, network_capacity=16, transparent=False,
+                 fp16=False, steps=1, lr=1e-4, fq_layers=[], fq_dict_size=256, attn_layers=[], aug=False,
+                 hist=64, device=None):
+        super().__init__()
+        if fp16:
+            raise NotImplementedError('fp16/apex is not offered: the MI355X path is fp32 (as the reference default)')
+        if aug:
+            raise NotImplementedError('DiffAugment (aug_prob > 0) is out of scope of the MI355X hot path')
+        self.lr = lr
+        self.aug = aug
+        self.steps = steps
+        self.ema_updater = EMA(0.995)
+        self.S = StyleVectorizer(latent_dim, style_depth)
+        self.H = HistVectorizer(hist, latent_dim, int(style_depth))
+        self.G = Generator(image_size, latent_dim, network_capacity, transparent=transparent)
+        self.D = Discriminator(image_size, network_capacity, fq_layers=fq_layers, fq_dict_size=fq_dict_size,
+                               attn_layers=attn_layers, transparent=transparent)
+        self.SE = StyleVectorizer(latent_dim, style_depth)
+        self.HE = HistVectorizer(hist, latent_dim, int(style_depth))
+        self.GE = Generator(image_size, latent_dim, network_capacity, transparent=transparent)
+        self.D_aug = None
+        set_requires_grad(self.SE, False)
+        set_requires_grad(self.HE, False)
+        set_requires_grad(self.GE, False)
+        self._init_weights()
+        self.reset_parameter_averaging()
+
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        self.to(device)
+        # flat storage (after the move): generator side in the reference's optimizer order G, S, H (:668-670)
+        self._flat_g = FlatParams(list(self.G.parameters()) + list(self.S.parameters()) + list(self.H.parameters()))
+        self._flat_d = FlatParams(self.D.parameters())
+        self._flat_ema = FlatParams(list(self.GE.parameters()) + list(self.SE.parameters()) +
+                                    list(self.HE.parameters()), with_grad=False)
+        self.G_opt = DiffGrad(self._flat_g, lr=self.lr, betas=(0.5, 0.9))
+        self.D_opt = DiffGrad(self._flat_d, lr=self.lr, betas=(0.5, 0.9))
+        # replicas start identical under data parallelism
+        for f in (self._flat_g, self._flat_d, self._flat_ema):
+            ddp.broadcast_flat(f)
+        self._reduce_g = ddp.GradAllReduce(self._flat_g)
+        self._reduce_d = ddp.GradAllReduce(self._flat_d)
+
+    def _init_weights(self):
+        for m in self.modules():
+            if type(m) in {nn.Conv2d, nn.Linear}:
+                nn.init.kaiming_normal_(m.weight, a=0, mode='fan_in', nonlinearity='leaky_relu')
+        for block in self.G.blocks:
+            nn.init.zeros_(block.to_noise1.weight)
+            nn.init.zeros_(block.to_noise2.weight)
+            nn.init.zeros_(block.to_noise1.bias)
+            nn.init.zeros_(block.to_noise2.bias)
+
+    def EMA(self):
+        ema_update(self._flat_ema, self._flat_g, self.ema_updater.beta)
+
+    def reset_parameter_averaging(self):
+        self.SE.load_state_dict(self.S.state_dict())
+        self.HE.load_state_dict(self.H.state_dict())
+        self.GE.load_state_dict(self.G.state_dict())
+
+    def forward(self, x):
+        return x
+
+
+class SyntheticData:
+    """Resident synthetic batches: images ~ U[0,1), target histograms = RGB-uv histograms of other random
+    images (sum 1, all bins > 0) -- SURVEY.md section 8d.  Replaces the reference's DataLoader for benchmarks."""
+
+    def __init__(self, hist_block, batch_size, image_size, device, pool=4, seed=0):
+        g = torch.Generator(device='cpu').manual_seed(seed)
+        self.batches = []
+        for _ in range(pool):
+            img = torch.rand(batch_size, 3, image_size, image_size, generator=g).to(device)
+            with torch.no_grad():
+                hist = hist_block(torch.rand(batch_size, 3, image_size, image_size, generator=g).to(device))
+            self.batches.append({'images': img, 'histograms': hist})
+        self.i = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        b = self.batches[self.i % len(self.batches)]
+        self.i += 1
+        return b
+
+
+class Trainer():
+    def __init__(self, name, results_dir, models_dir, image_size, network_capacity, transparent=False,
+                 batch_size=4, mixed_prob=0.9, gradient_accumulate_every=1, lr=2e-4, num_workers=None,
+                 save_every=1000, trunc_psi=0.6, fp16=False, fq_layers=[], fq_dict_size=256, attn_layers=[],
+                 hist_method='inverse-quadratic', hist_resizing='sampling', hist_sigma=0.02, hist_bin=64,
+                 hist_insz=150, aug_prob=0.0, dataset_aug_prob=0.0, aug_types=None, rng='device',
+                 *args, **kwargs):
+        from histogram_classes.RGBuvHistBlock import RGBuvHistBlock
+        if aug_types is None:
+            aug_types = ['translation', 'cutout']
+        self.GAN_params = [args, kwargs]
+        self.GAN = None
+        self.hist_method = hist_method
+        self.hist_resizing = hist_resizing
+        self.hist_sigma = hist_sigma
+        self.hist_bin = hist_bin
+        self.hist_insz = hist_insz
+        self.histBlock = RGBuvHistBlock(insz=self.hist_insz, h=self.hist_bin, method=self.hist_method,
+                                        resizing=self.hist_resizing, sigma=self.hist_sigma)
+        self.name = name
+        self.results_dir = Path(results_dir)
+        self.models_dir = Path(models_dir)
+        self.config_path = self.models_dir / name / '.config.json'
+        assert log2(image_size).is_integer(), 'image size must be a power of 2 (64, 128, 256, 512, 1024)'
+        self.image_size = image_size
+        self.network_capacity = network_capacity
+        self.transparent = transparent
+        self.fq_layers = cast_list(fq_layers)
+        self.fq_dict_size = fq_dict_size
+        self.attn_layers = cast_list(attn_layers)
+        self.aug_prob = aug_prob
+        self.aug_types = aug_types
+        self.dataset_aug_prob = dataset_aug_prob
+        self.lr = lr
+        self.batch_size = batch_size
+        self.num_workers = num_workers
+        self.mixed_prob = mixed_prob
+        self.save_every = save_every
+        self.steps = 0
+        self.av = None
+        self.trunc_psi = trunc_psi
+        self.pl_mean = 0
+        self.gradient_accumulate_every = gradient_accumulate_every
+        assert not fp16, 'fp16 is not offered on the MI355X path (fp32 only)'
+        self.fp16 = fp16
+        self.d_loss = 0
+        self.g_loss = 0
+        self.last_gp_loss = 0
+        self.last_cr_loss = 0
+        self.q_loss = 0
+        self.pl_length_ma = EMA(0.99)
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        self.rng = _Rng(self.device, rng)
+        self.is_main = ddp.rank() == 0
+        self.run_evaluate = True      # benchmarks switch evaluate()/save() off (excluded from the metric)
+        self.run_save = True
+        self.init_folders()
+        self.loader = None
+        self.loader_evaluate = None
+
+    def init_GAN(self):
+        args, kwargs = self.GAN_params
+        self.GAN = HistoGAN(lr=self.lr, image_size=self.image_size, network_capacity=self.network_capacity,
+                            transparent=self.transparent, fq_layers=self.fq_layers,
+                            fq_dict_size=self.fq_dict_size, attn_layers=self.attn_layers, fp16=self.fp16,
+                            hist=self.hist_bin, aug=self.aug_prob > 0, *args, **kwargs)
+
+    def write_config(self):
+        self.config_path.write_text(json.dumps(self.config()))
+
+    def load_config(self):
+        config = self.config() if not self.config_path.exists() else json.loads(self.config_path.read_text())
+        self.image_size = config['image_size']
+        self.network_capacity = config['network_capacity']
+        self.transparent = config['transparent']
+        self.fq_layers = config['fq_layers']
+        self.fq_dict_size = config['fq_dict_size']
+        self.attn_layers = config.pop('attn_layers', [])
+        del self.GAN
+        self.init_GAN()
+
+    def config(self):
+        return {'image_size': self.image_size, 'network_capacity': self.network_capacity,
+                'transparent': self.transparent, 'fq_layers': self.fq_layers,
+                'fq_dict_size': self.fq_dict_size, 'attn_layers': self.attn_layers}
+
+    def set_synthetic_data_src(self, pool=4, seed=None):
+        seed = ddp.rank() if seed is None else seed
+        self.loader = SyntheticData(self.histBlock, self.batch_size, self.image_size, self.device, pool, seed)
+        self.loader_evaluate = SyntheticData(self.histBlock, 4, min(self.image_size, 150), self.device, 1, seed + 977)
+
+    def set_data_src(self, folder):
+        from .data import FolderData
+        self.loader = FolderData(folder, self.histBlock, self.batch_size, self.image_size, self.device,
+                                 transparent=self.transparent, seed=ddp.rank())
+        self.loader_evaluate = FolderData(folder, self.histBlock, 4, self.image_size, self.device,
+                                          transparent=self.transparent, seed=977 + ddp.rank(), test=True)
+
+    # ------------------------------------------------------------------------------------------
+    def _w_and_hw(self, style, hist_batch):
+        GAN = self.GAN
+        w_space = latent_to_w(GAN.S, style)
+        h_w_space = GAN.H(hist_batch)
+        h_w_space = torch.unsqueeze(h_w_space, dim=1)
+        h_w_space = torch.cat((h_w_space, h_w_space), dim=1)
+        return styles_def_to_tensor(w_space), h_w_space
+
+    def train(self, alpha=2):
+        assert self.loader is not None, ('You must first initialize the data source with '
+                                         '`.set_data_src(<folder of images>)` or `.set_synthetic_data_src()`')
+        torch.autograd.set_detect_anomaly(False)
+        if self.GAN is None:
+            self.init_GAN()
+        GAN = self.GAN
+        GAN.train()
+        dev = self.device
+        zero = lambda: torch.zeros((), device=dev)
+        total_disc_loss, total_gen_loss, total_hist_loss = zero(), zero(), zero()
+        gp_val, q_val, pl_len = zero(), zero(), None
+
+        batch_size = self.batch_size
+        image_size = GAN.G.image_size
+        latent_dim = GAN.G.latent_dim
+        num_layers = GAN.G.num_layers
+        Disc = GAN.D
+        acc = self.gradient_accumulate_every
+        apply_gradient_penalty = self.steps % 4 == 0
+        apply_path_penalty = self.steps % 32 == 0
+
+        # ---- discriminator phase (reference :889-932)
+        GAN.D_opt.zero_grad()
+        for i in range(acc):
+            get_latents_fn = self.rng.mixed_list if random() < self.mixed_prob else self.rng.noise_list
+            style = get_latents_fn(batch_size, num_layers - 2, latent_dim)
+            noise = self.rng.image_noise(batch_size, image_size)
+            batch = next(self.loader)
+            image_batch = batch['images'].to(dev).detach().requires_grad_()
+            hist_batch = batch['histograms'].to(dev)
+            with torch.no_grad():   # the reference detaches this output; no graph is needed
+                w_styles, h_w_space = self._w_and_hw(style, hist_batch)
+                generated_images = GAN.G(w_styles, h_w_space, noise)
+            fake_output, fake_q_loss = Disc(generated_images)
+            real_output, real_q_loss = Disc(image_batch)
+            divergence = (F.relu(1 + real_output) + F.relu(1 - fake_output)).mean()
+            quantize_loss = (fake_q_loss + real_q_loss).mean()
+            q_val = quantize_loss.detach()
+            disc_loss = divergence + quantize_loss
+            if apply_gradient_penalty:
+                gp = gradient_penalty(image_batch, real_output)
+                gp_val = gp.detach()
+                disc_loss = disc_loss + gp
+            disc_loss = disc_loss / acc
+            disc_loss.backward()
+            total_disc_loss += divergence.detach() / acc
+        GAN._reduce_d.start()          # async all-reduce of D grads; overlaps the G forward below
+
+        # ---- generator phase (reference :934-989)
+        GAN.G_opt.zero_grad()
+        d_updated = False
+        for i in range(acc):
+            style = get_latents_fn(batch_size, num_layers - 2, latent_dim)
+            noise = self.rng.image_noise(batch_size, image_size)
+            batch = next(self.loader)
+            hist_batch = batch['histograms'].to(dev)
+            w_styles, h_w_space = self._w_and_hw(style, hist_batch)
+            generated_images = GAN.G(w_styles, h_w_space, noise)
+            if not d_updated:           # D must be updated before it scores the new fakes (reference order)
+                GAN._reduce_d.finish()
+                GAN.D_opt.step()
+                d_updated = True
+            fake_output, _ = Disc(generated_images)
+            generated_histograms = self.histBlock(F.relu(generated_images))
+            histogram_loss = hellinger_loss(hist_batch, generated_histograms, alpha)
+            loss = fake_output.mean()
+            gen_loss = loss + histogram_loss
+            if apply_path_penalty:
+                std = 0.1 / (w_styles.std(dim=0, keepdim=True) + EPS)
+                w_styles_2 = w_styles + self.rng.randn_like(w_styles) / (std + EPS)
+                pl_images = GAN.G(w_styles_2, h_w_space, noise)
+                pl_lengths = ((pl_images - generated_images) ** 2).mean(dim=(1, 2, 3))
+                pl_len = pl_lengths.detach().mean()
+                if not is_empty(self.pl_mean):
+                    pl_loss = ((pl_lengths - self.pl_mean) ** 2).mean()
+                    # reference: added only if not NaN (:974) -- nan_to_num keeps that without a host sync
+                    gen_loss = gen_loss + torch.where(torch.isnan(pl_loss), torch.zeros_like(pl_loss), pl_loss)
+            gen_loss = gen_loss / acc
+            gen_loss.backward()
+            total_gen_loss += loss.detach() / acc
+            total_hist_loss += histogram_loss.detach() / acc
+        GAN._reduce_g()
+        GAN.G_opt.step()
+
+        # ---- one read-back for everything the host needs (reference: >= 7 syncs)
+        stats = torch.stack([total_disc_loss, total_gen_loss, total_hist_loss, gp_val.reshape(()),
+                             q_val.reshape(()), pl_len if pl_len is not None else zero()]).double()
+        if ddp.is_dist():
+            nan_flag = torch.isnan(stats[:2]).any().double().reshape(1)
+            packed = torch.cat([stats, nan_flag])
+            torch.distributed.all_reduce(packed[:6], op=torch.distributed.ReduceOp.SUM)
+            torch.distributed.all_reduce(packed[6:], op=torch.distributed.ReduceOp.MAX)
+            packed[:6] /= ddp.world_size()
+            host = packed.cpu().numpy()
+            has_nan = host[6] > 0 or np.isnan(host[:2]).any()
+        else:
+            host = stats.cpu().numpy()
+            has_nan = bool(np.isnan(host[:2]).any())
+        self.d_loss, self.g_loss, self.h_loss = float(host[0]), float(host[1]), float(host[2])
+        if apply_gradient_penalty:
+            self.last_gp_loss = float(host[3])
+        self.q_loss = float(host[4])
+
+        # moving averages (reference :991-1000)
+        if apply_path_penalty and not np.isnan(host[5]):
+            self.pl_mean = self.pl_length_ma.update_average(self.pl_mean, float(host[5]))
+        if self.steps % 10 == 0 and self.steps > 20000:
+            GAN.EMA()
+        if self.steps <= 25000 and self.steps % 1000 == 2:
+            GAN.reset_parameter_averaging()
+
+        # save from NaN errors (reference :1002-1010); the flag is all-reduced so every rank raises
+        checkpoint_num = floor(self.steps / self.save_every)
+        if has_nan:
+            print(f'NaN detected for generator or discriminator. Loading from checkpoint #{checkpoint_num}')
+            self.load(checkpoint_num)
+            raise NanException
+
+        if self.run_save and self.steps % self.save_every == 0:
+            self.save(checkpoint_num)
+        if self.run_evaluate and (self.steps % 1000 == 0 or (self.steps % 100 == 0 and self.steps < 2500)):
+            self.evaluate(floor(self.steps / 1000))
+        self.steps += 1
+        self.av = None
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def evaluate(self, num=0, hist_batch=None, num_image_tiles=4, latents=None, n=None, save_noise_latent=False,
+                 load_noise_file=None, load_latent_file=None):
+        self.GAN.eval()
+        if hist_batch is None:
+            batch = next(self.loader_evaluate)
+            hist_batch = batch['histograms'].to(self.device)
+        ext = 'jpg' if not self.transparent else 'png'
+        num_rows = num_image_tiles
+        if latents is None and n is None:
+            latent_dim = self.GAN.G.latent_dim
+            image_size = self.GAN.G.image_size
+            num_layers = self.GAN.G.num_layers
+            if load_noise_file is not None:
+                n = torch.tensor(np.load(load_noise_file)).to(self.device)
+            else:
+                n = self.rng.image_noise(num_rows ** 2, image_size)
+            if load_latent_file is not None:
+                latents = np.load(load_latent_file)
+            else:
+                latents = self.rng.noise_list(num_rows ** 2, num_layers - 2, latent_dim)
+        generated_images = self.generate_truncated(self.GAN.SE, self.GAN.HE, self.GAN.GE, hist_batch, latents, n,
+                                                   trunc_psi=self.trunc_psi)
+        if num is not None and self.is_main:
+            from .data import save_image_grid
+            save_image_grid(generated_images, str(self.results_dir / self.name / f'{str(num)}-ema.{ext}'),
+                            nrow=num_rows)
+        if save_noise_latent:
+            Path(f'temp/{self.name}').mkdir(parents=True, exist_ok=True)
+            np.save(f'temp/{self.name}/{str(num)}-noise.npy', n.clone().cpu().numpy())
+            np.save(f'temp/{self.name}/{str(num)}-latents.npy', latents)
+        return generated_images
+
+    @torch.no_grad()
+    def generate_truncated(self, S, H, G, hist_batch, style, noi, trunc_psi=0.75):
+        latent_dim = G.latent_dim
+        if self.av is None:
+            z = self.rng.noise(2000, latent_dim)
+            samples = evaluate_in_chunks(self.batch_size, S, z).cpu().numpy()
+            self.av = np.mean(samples, axis=0)
+            self.av = np.expand_dims(self.av, axis=0)
+        w_space = []
+        for tensor, num_layers in style:
+            tmp = S(tensor)
+            av_torch = torch.from_numpy(self.av).to(self.device)
+            tmp = trunc_psi * (tmp - av_torch) + av_torch
+            w_space.append((tmp, num_layers))
+        h_w_space = H(hist_batch)
+        h_w_space = torch.unsqueeze(h_w_space, dim=1)
+        h_w_space = torch.cat((h_w_space, h_w_space), dim=1)
+        for i in range(int(np.log2(np.sqrt(w_space[0][0].shape[0])))):
+            h_w_space = torch.cat((h_w_space, h_w_space), dim=0)
+        w_styles = styles_def_to_tensor(w_space)
+        generated_images = evaluate_in_chunks(self.batch_size, G, w_styles, h_w_space, noi)
+        return generated_images.clamp_(0.0, 1.0)
+
+    def print_log(self):
+        if not self.is_main:
+            return
+        if hasattr(self, 'h_loss'):
+            print(f'\nG: {self.g_loss:.2f} | H: {self.h_loss:.2f} | D: {self.d_loss:.2f} | GP: '
+                  f'{self.last_gp_loss:.2f} | PL: {self.pl_mean:.2f} | CR: {self.last_cr_loss:.2f} | Q: '
+                  f'{self.q_loss:.2f}')
+        else:
+            print(f'\nG: {self.g_loss:.2f} | D: {self.d_loss:.2f} | GP: {self.last_gp_loss:.2f} | PL: '
+                  f'{self.pl_mean:.2f} | CR: {self.last_cr_loss:.2f} | Q: {self.q_loss:.2f}')
+
+    def model_name(self, num):
+        return str(self.models_dir / self.name / f'model_{num}.pt')
+
+    def init_folders(self):
+        (self.results_dir / self.name).mkdir(parents=True, exist_ok=True)
+        (self.models_dir / self.name).mkdir(parents=True, exist_ok=True)
+
+    def clear(self):
+        rmtree(f'./models/{self.name}', True)
+        rmtree(f'./results/{self.name}', True)
+        rmtree(str(self.config_path), True)
+        self.init_folders()
+
+    def save(self, num):
+        if self.is_main:       # rank 0 alone writes (replicas are identical)
+            torch.save(self.GAN.state_dict(), self.model_name(num))
+            self.write_config()
+
+    def load(self, num=-1):
+        self.load_config()
+        name = num
+        if num == -1:
+            file_paths = [p for p in Path(self.models_dir / self.name).glob('model_*.pt')]
+            saved_nums = sorted(map(lambda x: int(x.stem.split('_')[1]), file_paths))
+            if len(saved_nums) == 0:
+                return
+            name = saved_nums[-1]
+            print(f'continuing from previous epoch - {name}')
+        self.steps = name * self.save_every
+        self.GAN.load_state_dict(torch.load(self.model_name(name), map_location=self.device))

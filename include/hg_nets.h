@@ -1,0 +1,59 @@
+/* hg_nets.h -- C ABI of the generator/optimizer elementwise kernels (libhistogan_hip.so).
+ *
+ * These replace the aten op-chains around the dense contraction of the reference's modulated
+ * convolution and its optimizer:
+ *   Conv2DMod.forward            histoGAN/histoGAN.py:420-440   (activation-modulation form:
+ *                                conv(x*(s+1), W) * d  ==  grouped conv with per-sample weights)
+ *   nn.Upsample(bilinear x2)     histoGAN/histoGAN.py:377-378, 447-448, 462-463
+ *   noise add + LeakyReLU(0.2)   histoGAN/histoGAN.py:465-476   (noise permute (0,3,2,1): H<->W)
+ *   DiffGrad.step                torch_optimizer (third-party), ctor at histoGAN/histoGAN.py:670-671
+ *   HistoGAN.EMA                 histoGAN/histoGAN.py:698-707
+ *
+ * Conventions as in hg_hist.h: return 0 / negative HG_E* / positive hipError_t; device pointers;
+ * fp32; contiguous NCHW; enqueue on `stream`; never allocate or synchronise.
+ */
+#ifndef HG_NETS_H
+#define HG_NETS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[b,c,:,:] = up(x[b,c,:,:]) * (s[b,c] + 1);  up = identity (upsample=0) or bilinear x2
+ * (align_corners=False, edge clamp).  x: (B,C,H,W); out: (B,C,H*f,W*f), f = upsample ? 2 : 1.
+ * s may be NULL (no modulation: plain upsample). */
+int hg_modulate_fwd(const float *x, const float *s, float *out, int32_t B, int32_t C, int32_t H, int32_t W,
+                    int32_t upsample, void *stream);
+/* gx = up^T(gout * (s+1));  gs[b,c] = sum(gout * up(x))  (gs may be NULL when s is NULL). */
+int hg_modulate_bwd(const float *gout, const float *x, const float *s, float *gx, float *gs, int32_t B,
+                    int32_t C, int32_t H, int32_t W, int32_t upsample, void *stream);
+
+/* out[b,o,i,j] = lrelu_0.2( conv[b,o,i,j] * d[b,o] + wn[o] * nzt[b,i,j] + bn[o] )
+ * conv/out: (B,O,H,H);  d: (B,O) or NULL (no demodulation);  wn, bn: (O) = to_noise Linear(1,O);
+ * nzt: (B,S,S), S >= H, the noise image ALREADY TRANSPOSED (nzt[b][i][j] = inoise[b][j][i][0]):
+ * the reference's `.permute((0,3,2,1))` swaps H and W, so position (i,j) sees inoise[b,j,i]. */
+int hg_demod_noise_lrelu_fwd(const float *conv, const float *d, const float *nzt, const float *wn,
+                             const float *bn, float *out, int32_t B, int32_t O, int32_t H, int32_t S,
+                             void *stream);
+/* m = gout * (out > 0 ? 1 : 0.2):  gconv = m * d;  gd[b,o] = sum m*conv  (gd may be NULL when d is);
+ * gwn_part[b,o] = sum m * nzt[b,i,j];  gbn_part[b,o] = sum m   (caller sums the parts over b). */
+int hg_demod_noise_lrelu_bwd(const float *gout, const float *out, const float *conv, const float *d,
+                             const float *nzt, float *gconv, float *gd, float *gwn_part, float *gbn_part,
+                             int32_t B, int32_t O, int32_t H, int32_t S, void *stream);
+
+/* Fused multi-tensor DiffGrad step over one flat parameter buffer of n floats:
+ *   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  dfc = 1/(1+exp(-|g_prev-g|));  g_prev = g
+ *   p -= lr*sqrt(1-b2^t)/(1-b1^t) * (m*dfc) / (sqrt(v)+eps)                         (t = step >= 1) */
+int hg_diffgrad_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, float *prev_grad,
+                     int64_t n, float lr, float beta1, float beta2, float eps, int32_t step, void *stream);
+
+/* ma = beta*ma + (1-beta)*p over a flat buffer (HistoGAN.EMA). */
+int hg_ema_update(float *ma, const float *p, int64_t n, float beta, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HG_NETS_H */

@@ -1,0 +1,293 @@
+"""GPU parity of the generator kernels / network modules / optimizer / train step against
+(a) golden vectors from the reference's own classes and (b) the functional oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN_DIR, relmax
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def g():
+    z = np.load(os.path.join(GOLDEN_DIR, 'nets_small.npz'))
+    return {k: z[k] for k in z.files}
+
+
+def sd_of(g, prefix, dev):
+    return {k[len(prefix) + 1:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith(prefix + '/')}
+
+
+def T(a, dev, grad=False):
+    t = torch.from_numpy(np.asarray(a)).to(dev)
+    return t.requires_grad_(True) if grad else t
+
+
+# ---- kernels vs plain torch ------------------------------------------------------------------
+@pytest.mark.parametrize('shape,up', [((2, 5, 4, 4), False), ((2, 5, 4, 4), True), ((3, 7, 16, 16), True),
+                                      ((1, 3, 32, 32), True), ((2, 4, 64, 64), False), ((2, 3, 2, 2), True)])
+def test_modulate_matches_torch(shape, up, gpu_device):
+    from histogan_amd import ops
+    torch.manual_seed(1)
+    x = torch.randn(*shape, device=gpu_device, requires_grad=True)
+    s = torch.randn(shape[0], shape[1], device=gpu_device, requires_grad=True)
+    ref = (F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) if up else x) * (s + 1)[:, :, None, None]
+    out = ops.modulate(x, s, up)
+    assert relmax(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-6
+    go = torch.randn_like(ref)
+    gr = torch.autograd.grad(ref, (x, s), go)
+    gm = torch.autograd.grad(out, (x, s), go)
+    for a, b in zip(gm, gr):
+        assert relmax(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+
+
+def test_upsample2x_matches_torch(gpu_device):
+    from histogan_amd import ops
+    x = torch.randn(2, 3, 8, 8, device=gpu_device, requires_grad=True)
+    ref = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False)
+    out = ops.upsample2x(x)
+    assert relmax(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-6
+    go = torch.randn_like(ref)
+    assert relmax(torch.autograd.grad(out, x, go)[0].cpu().numpy(),
+                  torch.autograd.grad(ref, x, go)[0].cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.parametrize('H,O,demod', [(4, 6, True), (16, 5, True), (32, 3, False)])
+def test_demod_noise_lrelu_matches_torch(H, O, demod, gpu_device):
+    from histogan_amd import ops
+    torch.manual_seed(2)
+    B, S = 2, 64
+    conv = torch.randn(B, O, H, H, device=gpu_device, requires_grad=True)
+    d = (torch.rand(B, O, device=gpu_device) + 0.5).requires_grad_(True) if demod else None
+    inoise = torch.rand(B, S, S, 1, device=gpu_device)
+    lin = torch.nn.Linear(1, O).to(gpu_device)
+    noise = lin(inoise[:, :H, :H, :]).permute(0, 3, 2, 1)          # the reference's expression (:465-467)
+    ref = F.leaky_relu((conv * d[:, :, None, None] if demod else conv) + noise, 0.2)
+    out = ops.demod_noise_lrelu(conv, d, inoise[..., 0].transpose(1, 2).contiguous(), lin.weight, lin.bias)
+    assert relmax(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-6
+    go = torch.randn_like(ref)
+    ins = [conv, lin.weight, lin.bias] + ([d] if demod else [])
+    gr = torch.autograd.grad(ref, ins, go)
+    gm = torch.autograd.grad(out, ins, go)
+    for a, b in zip(gm, gr):
+        assert relmax(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+
+
+# ---- modules vs goldens of the reference classes ---------------------------------------------
+@pytest.mark.parametrize('tag,k,demod', [('c3', 3, True), ('c1', 1, False)])
+def test_conv2dmod_golden(g, tag, k, demod, gpu_device):
+    from histoGAN import Conv2DMod
+    w = g[f'{tag}/weight']
+    conv = Conv2DMod(w.shape[1], w.shape[0], k, demod=demod).to(gpu_device)
+    with torch.no_grad():
+        conv.weight.copy_(T(w, gpu_device))
+    x, y = T(g[f'{tag}/x'], gpu_device, True), T(g[f'{tag}/y'], gpu_device, True)
+    o = conv(x, y)
+    assert relmax(o.detach().cpu().numpy(), g[f'{tag}/out']) <= 1e-5
+    gx, gy, gw = torch.autograd.grad(o, (x, y, conv.weight), T(g[f'{tag}/go'], gpu_device))
+    for a, name in ((gx, 'gx'), (gy, 'gy'), (gw, 'gw')):
+        assert relmax(a.cpu().numpy(), g[f'{tag}/{name}']) <= 1e-4
+
+
+def test_generator_golden(g, gpu_device):
+    from histoGAN import Generator
+    S_, CAP, LAT, HB, B, L = [int(v) for v in g['meta']]
+    G = Generator(S_, LAT, network_capacity=CAP).to(gpu_device)
+    G.load_state_dict(sd_of(g, 'G', gpu_device))
+    styles, hists = T(g['g_styles'], gpu_device, True), T(g['g_hists'], gpu_device, True)
+    rgb = G(styles, hists, T(g['g_noise'], gpu_device))
+    assert relmax(rgb.detach().cpu().numpy(), g['g_rgb']) <= 1e-5
+    names = [k[len('g_grad/'):] for k in g if k.startswith('g_grad/')]
+    params = dict(G.named_parameters())
+    grads = torch.autograd.grad(rgb, [styles, hists] + [params[n] for n in names], T(g['g_go'], gpu_device))
+    assert relmax(grads[0].cpu().numpy(), g['g_grad_styles']) <= 1e-4
+    assert relmax(grads[1].cpu().numpy(), g['g_grad_hists']) <= 1e-4
+    for n, gr in zip(names, grads[2:]):
+        assert relmax(gr.cpu().numpy(), g[f'g_grad/{n}']) <= 1e-4, n
+
+
+def test_discriminator_and_gp_golden(g, gpu_device):
+    from histoGAN import Discriminator
+    from histoGAN.histoGAN import gradient_penalty
+    S_, CAP = int(g['meta'][0]), int(g['meta'][1])
+    D = Discriminator(S_, network_capacity=CAP).to(gpu_device)
+    D.load_state_dict(sd_of(g, 'D', gpu_device))
+    img = T(g['d_img'], gpu_device, True)
+    logits, q = D(img)
+    assert relmax(logits.detach().cpu().numpy(), g['d_logits']) <= 1e-5
+    gp = gradient_penalty(img, logits)
+    assert abs(float(gp) - float(g['d_gp'])) <= 1e-4 * max(1.0, abs(float(g['d_gp'])))
+    loss = torch.relu(1 + logits).mean() + gp
+    names = [k[len('d_grad/'):] for k in g if k.startswith('d_grad/')]
+    params = dict(D.named_parameters())
+    for n, gr in zip(names, torch.autograd.grad(loss, [params[n] for n in names])):
+        assert relmax(gr.cpu().numpy(), g[f'd_grad/{n}']) <= 1e-4, n
+
+
+def test_vectorizers_golden(g, gpu_device):
+    from histoGAN import HistVectorizer
+    from histoGAN.histoGAN import StyleVectorizer
+    S_, CAP, LAT, HB, B, L = [int(v) for v in g['meta']]
+    sv = StyleVectorizer(LAT, 3).to(gpu_device); sv.load_state_dict(sd_of(g, 'S', gpu_device))
+    hv = HistVectorizer(HB, LAT, 3).to(gpu_device); hv.load_state_dict(sd_of(g, 'H', gpu_device))
+    assert relmax(sv(T(g['z'], gpu_device)).detach().cpu().numpy(), g['w']) <= 1e-5
+    assert relmax(hv(T(g['hist'], gpu_device)).detach().cpu().numpy(), g['hw']) <= 1e-5
+
+
+# ---- optimizer --------------------------------------------------------------------------------
+def test_diffgrad_and_ema_match_oracle(gpu_device):
+    from histogan_amd.optim import DiffGrad, FlatParams, ema_update
+    from oracle import histogan_nets as N
+    torch.manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(s, device=gpu_device)) for s in ((7, 5), (33,), (4, 3, 3, 3))]
+    ref = [p.detach().cpu().clone() for p in ps]
+    states = [dict(step=0, exp_avg=torch.zeros_like(r), exp_avg_sq=torch.zeros_like(r),
+                   previous_grad=torch.zeros_like(r)) for r in ref]
+    opt = DiffGrad(ps, lr=2e-4, betas=(0.5, 0.9))
+    for it in range(5):
+        opt.zero_grad()
+        gs = [torch.randn_like(r) * (0.1 + it) for r in ref]
+        for p, gr in zip(ps, gs):
+            p.grad.copy_(gr.to(gpu_device))
+        opt.step()
+        for r, gr, stt in zip(ref, gs, states):
+            N.diffgrad_step(r, gr, stt, lr=2e-4, betas=(0.5, 0.9))
+    for p, r in zip(ps, ref):
+        assert relmax(p.detach().cpu().numpy(), r.numpy()) <= 1e-6
+    ma = [torch.nn.Parameter(torch.randn_like(p)) for p in ps]
+    ma_ref = [m.detach().cpu().clone() for m in ma]
+    fm = FlatParams(ma, with_grad=False)
+    ema_update(fm, opt.flat, 0.995)
+    for m, mr, p in zip(ma, ma_ref, ps):
+        assert relmax(m.detach().cpu().numpy(), (mr * 0.995 + 0.005 * p.detach().cpu()).numpy()) <= 1e-6
+
+
+# ---- whole train step vs the oracle ------------------------------------------------------------
+class _ReplayRng:
+    """Feeds Trainer.train the tensors the oracle step uses (same draw order as the reference)."""
+
+    def __init__(self, device, B, L, LAT, S, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.dev = device
+        self.z = [torch.randn(B, LAT, generator=g) for _ in range(4)]
+        self.img_noise = [torch.rand(B, S, S, 1, generator=g) for _ in range(2)]
+        self.pl = torch.randn(B, L - 2, LAT, generator=g)
+        self.zi = self.ni = 0
+        self.tt = 1
+
+    def noise(self, n, d):
+        z = self.z[self.zi]; self.zi += 1
+        return z.to(self.dev)
+
+    def noise_list(self, n, layers, d):
+        return [(self.noise(n, d), layers)]
+
+    def mixed_list(self, n, layers, d):
+        return self.noise_list(n, self.tt, d) + self.noise_list(n, layers - self.tt, d)
+
+    def image_noise(self, n, s):
+        x = self.img_noise[self.ni]; self.ni += 1
+        return x.to(self.dev)
+
+    def randn_like(self, t):
+        return self.pl.to(self.dev)
+
+
+def test_train_step_matches_oracle(gpu_device, tmp_path):
+    """One Trainer.train() step at step 0 (gradient penalty AND path-length regulariser active) against
+    the same step evaluated with oracle/ (functional nets + oracle histogram + oracle DiffGrad) on CPU."""
+    from histoGAN import Trainer
+    from oracle import histogan_nets as N
+    from oracle import rgbuv_hist as OH
+    torch.manual_seed(11)
+    S_, CAP, B, HB, ALPHA, LR = 32, 4, 2, 16, 2.0, 2e-4
+    tr = Trainer('t', tmp_path / 'r', tmp_path / 'm', S_, CAP, batch_size=B, lr=LR, hist_bin=HB, hist_insz=150,
+                 hist_resizing='interpolation', mixed_prob=1.1)
+    tr.run_evaluate = tr.run_save = False
+    tr.init_GAN()
+    GAN = tr.GAN
+    with torch.no_grad():   # exercise the noise path (zero-initialised in the reference)
+        for blk in GAN.G.blocks:
+            blk.to_noise1.weight.normal_(std=0.3); blk.to_noise2.weight.normal_(std=0.3)
+    L, LAT = GAN.G.num_layers, GAN.G.latent_dim
+    sd0 = {k: v.detach().cpu().clone() for k, v in GAN.state_dict().items()}
+    gen = torch.Generator().manual_seed(5)
+    batches = []
+    for _ in range(2):
+        img = torch.rand(B, 3, S_, S_, generator=gen)
+        hist = OH.rgbuv_hist(torch.rand(B, 3, S_, S_, generator=gen), h=HB)
+        batches.append({'images': img, 'histograms': hist})
+    tr.loader = iter([{k: v.to(gpu_device) for k, v in b.items()} for b in batches])
+    rr = _ReplayRng(gpu_device, B, L, LAT, S_, 77)
+    tr.rng = rr
+    tr.train(alpha=ALPHA)
+    new = {k: v.detach().cpu() for k, v in GAN.state_dict().items()}
+
+    # ---- oracle step on CPU
+    rc = _ReplayRng(torch.device('cpu'), B, L, LAT, S_, 77)
+    sub = lambda p: {k[len(p) + 1:]: sd0[k].clone().requires_grad_(True) for k in sd0 if k.startswith(p + '.')}
+    sG, sD, sS, sH = sub('G'), sub('D'), sub('S'), sub('H')
+    nblk = L + 1
+
+    def w_hw(style, hist):
+        w = [(N.vectorizer(sS, z, 'net'), n) for z, n in style]
+        hw = N.vectorizer(sH, hist, 'fcs')[:, None, :]
+        return N.styles_def_to_tensor(w), torch.cat((hw, hw), 1)
+
+    # D phase
+    style = rc.mixed_list(B, L - 2, LAT); noise = rc.image_noise(B, S_)
+    img = batches[0]['images'].clone().requires_grad_(True)
+    with torch.no_grad():
+        w, hw = w_hw(style, batches[0]['histograms'])
+        fake = N.generator(sG, w, hw, noise, L)
+    real_out = N.discriminator(sD, img, nblk)
+    fake_out = N.discriminator(sD, fake, nblk)
+    div = (F.relu(1 + real_out) + F.relu(1 - fake_out)).mean()
+    d_loss = div + N.gradient_penalty(img, real_out)
+    dk = list(sD.keys())
+    dgr = torch.autograd.grad(d_loss, [sD[k] for k in dk])
+    for k, gr in zip(dk, dgr):
+        st = dict(step=0, exp_avg=torch.zeros_like(gr), exp_avg_sq=torch.zeros_like(gr), previous_grad=torch.zeros_like(gr))
+        with torch.no_grad():
+            N.diffgrad_step(sD[k], gr, st, lr=LR, betas=(0.5, 0.9))
+    # G phase (uses the UPDATED discriminator)
+    style = rc.mixed_list(B, L - 2, LAT); noise = rc.image_noise(B, S_)
+    w, hw = w_hw(style, batches[1]['histograms'])
+    gen_img = N.generator(sG, w, hw, noise, L)
+    fo = N.discriminator(sD, gen_img, nblk)
+    gh = OH.rgbuv_hist(F.relu(gen_img), h=HB)
+    h_loss = OH.hellinger_loss(batches[1]['histograms'], gh, ALPHA)
+    g_loss = fo.mean() + h_loss
+    std = 0.1 / (w.std(dim=0, keepdim=True) + 1e-8)
+    w2 = w + rc.randn_like(w) / (std + 1e-8)
+    pl = ((N.generator(sG, w2, hw, noise, L) - gen_img) ** 2).mean(dim=(1, 2, 3))
+    g_loss = g_loss + ((pl - 0) ** 2).mean()
+    groups = [('G', sG), ('S', sS), ('H', sH)]
+    keys = [(p, k) for p, s in groups for k in s]
+    ggr = torch.autograd.grad(g_loss, [dict(groups)[p][k] for p, k in keys])
+    for (p, k), gr in zip(keys, ggr):
+        st = dict(step=0, exp_avg=torch.zeros_like(gr), exp_avg_sq=torch.zeros_like(gr), previous_grad=torch.zeros_like(gr))
+        with torch.no_grad():
+            N.diffgrad_step(dict(groups)[p][k], gr, st, lr=LR, betas=(0.5, 0.9))
+
+    assert abs(tr.d_loss - float(div)) <= 1e-4
+    assert abs(tr.g_loss - float(fo.mean())) <= 1e-4
+    assert abs(tr.h_loss - float(h_loss)) <= 1e-4
+    # generator-side gradients are still in the flat buffer (zeroed at the start of the next step)
+    for (p, k), gr in zip(keys, ggr):
+        mine = dict(getattr(GAN, p).named_parameters())[k].grad.detach().cpu().numpy()
+        assert relmax(mine, gr.numpy()) <= 1e-3, (p, k)
+    # parameters after the step.  The first DiffGrad step is ~ lr*sigmoid(|g|)*g/(|g|+3e-8): compare the
+    # deltas where the gradient is not rounding noise (elsewhere the sign itself is ill-conditioned)
+    for (p, s), grads in ((('D', sD), dict(zip(dk, dgr))),) + tuple(
+            ((p, s), {k: gr for (pp, k), gr in zip(keys, ggr) if pp == p}) for p, s in groups):
+        for k, v in s.items():
+            gr = grads[k].numpy()
+            mask = np.abs(gr) > 1e-4 * np.abs(gr).max()
+            dn = (new[f'{p}.{k}'] - sd0[f'{p}.{k}']).numpy()
+            do = (v.detach() - sd0[f'{p}.{k}']).numpy()
+            assert np.max(np.abs(dn - do)[mask]) <= 0.02 * LR, (p, k)
