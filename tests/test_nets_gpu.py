@@ -290,7 +290,7 @@ def test_train_step_matches_oracle(gpu_device, tmp_path):
             ((p, s), {k: gr for (pp, k), gr in zip(keys, ggr) if pp == p}) for p, s in groups):
         for k, v in s.items():
             gr = grads[k].numpy()
-            mask = np.abs(gr) > 1e-4 * np.abs(gr).max()
+            mask = np.abs(gr) > 5e-2 * np.abs(gr).max()   # well above the gradient tolerance: sign is certain
             dn = (new[f'{p}.{k}'] - sd0[f'{p}.{k}']).numpy()
             do = (v.detach() - sd0[f'{p}.{k}']).numpy()
             assert np.max(np.abs(dn - do)[mask]) <= 0.02 * LR, (p, k)
