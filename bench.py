@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- hot-path benchmark (contract: one JSON line on rank 0).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload hist|train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|hist]
 
-Workload `hist` (BASELINE.json configs[1]): RGB-uv histogram forward + Hellinger loss + backward
-on a resident synthetic batch 32x3x256x256 fp32, h=64, inverse-quadratic sigma=0.02, insz=256
-(N = 65 536 pixels per image).  One step = one pass over one batch.  Multi-GPU: every rank runs
-the same per-rank batch (weak scaling, no data-path collective -- images are independent,
-SURVEY.md section 8e); value = images of all ranks / max-over-ranks time.
+Workload `train` (default; BASELINE.json configs[2], and configs[3] under --gpus 8): the full HistoGAN
+G+D train step (histogan_amd/trainer.py == reference Trainer.train, histoGAN/histoGAN.py:853-1020) at
+256^2, network_capacity 16, h=64, batch 32 PER GPU on resident synthetic data; the K timed steps
+follow W warm-up steps, so with the defaults (W=4, K=32) they contain 8 gradient-penalty steps and
+1 path-length step -- the reference's steady-state mix.  evaluate()/save() are excluded.  Multi-GPU:
+one process per GPU, RCCL all-reduce of the flat gradient buffers (weak scaling).
+
+Workload `hist` (BASELINE.json configs[1]): RGB-uv histogram forward + Hellinger loss + backward on a
+resident batch 32x3x256x256, h=64, inverse-quadratic sigma=0.02, insz=256 (N = 65 536 pixels/image).
+
+Both report `roofline` for the hand-written dominant histogram kernel (k_hist_bwd, timed with HIP events
+around the C-ABI calls at the configs[1] shape) and `cpu_baseline` (the oracle on host cores).
 """
 import argparse
 import json
@@ -81,6 +88,27 @@ def hist_workload(args, dev, rank, world):
                                     bytes_bwd=bytes_bwd), info, B
 
 
+def train_workload(args, dev, rank, world):
+    from histoGAN import Trainer
+    tr = Trainer('bench', '/tmp/hg_bench_results', '/tmp/hg_bench_models', args.size, args.capacity,
+                 batch_size=args.batch, hist_bin=args.bins, hist_insz=150, hist_resizing='interpolation',
+                 hist_method='inverse-quadratic', hist_sigma=0.02)
+    tr.run_evaluate = tr.run_save = False
+    tr.set_synthetic_data_src()
+    tr.init_GAN()
+
+    def step():
+        tr.train(alpha=2)
+
+    info = dict(workload=f'HistoGAN G+D train step {args.size}x{args.size} capacity={args.capacity} '
+                         f'batch={args.batch}/GPU h={args.bins} insz=150 inverse-quadratic (GP every 4th, PL every 32nd step)',
+                batch_per_gpu=args.batch, global_batch=args.batch * world, image_size=args.size,
+                network_capacity=args.capacity, h=args.bins, parallelism=f'dp{world}',
+                params_G=sum(p.numel() for p in tr.GAN.G.parameters()),
+                params_D=sum(p.numel() for p in tr.GAN.D.parameters()))
+    return step, info, args.batch
+
+
 def cpu_baseline(args):
     """The oracle (port of the reference's PyTorch CPU path) on a bounded sample of the workload."""
     from oracle import rgbuv_hist as O
@@ -101,9 +129,10 @@ def cpu_baseline(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='hist')
+    ap.add_argument('--steps', type=int, default=32)
+    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--workload', default='train', choices=['train', 'hist'])
+    ap.add_argument('--capacity', type=int, default=16)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--bins', type=int, default=64)
@@ -122,7 +151,11 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    step, time_kernels, work, info, units = hist_workload(args, dev, rank, world)
+    hstep, time_kernels, work, hinfo, units = hist_workload(args, dev, rank, world)
+    if args.workload == 'train':
+        step, info, units = train_workload(args, dev, rank, world)
+    else:
+        step, info = hstep, hinfo
 
     for _ in range(args.warmup):
         step()

