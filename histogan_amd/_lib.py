@@ -69,16 +69,29 @@ def _load():
     lib.hg_diffgrad_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]
     lib.hg_ema_update.restype = ctypes.c_int
     lib.hg_ema_update.argtypes = [vp, vp, i64, f32, vp]
+    # include/hg_conv.h
+    lib.hg_conv_packed_elems.restype = sz
+    lib.hg_conv_packed_elems.argtypes = [i32, i32, i32, i32]
+    lib.hg_conv_pack_weights.restype = ctypes.c_int
+    lib.hg_conv_pack_weights.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    lib.hg_conv2d_same.restype = ctypes.c_int
+    lib.hg_conv2d_same.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.hg_conv2d_wgrad_workspace_bytes.restype = sz
+    lib.hg_conv2d_wgrad_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32]
+    lib.hg_conv2d_wgrad.restype = ctypes.c_int
+    lib.hg_conv2d_wgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, sz, vp]
     return lib
 
 
 lib = _load()
 
-# every symbol include/hg_hist.h declares
+# every symbol include/hg_hist.h, hg_nets.h and hg_conv.h declare
 EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_fwd',
            'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd',
            'hg_modulate_fwd', 'hg_modulate_bwd', 'hg_demod_noise_lrelu_fwd', 'hg_demod_noise_lrelu_bwd',
-           'hg_diffgrad_step', 'hg_ema_update')
+           'hg_diffgrad_step', 'hg_ema_update',
+           'hg_conv_packed_elems', 'hg_conv_pack_weights', 'hg_conv2d_same', 'hg_conv2d_wgrad_workspace_bytes',
+           'hg_conv2d_wgrad')
 
 
 class HgError(RuntimeError):

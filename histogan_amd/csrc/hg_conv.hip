@@ -1,0 +1,616 @@
+// hg_conv.hip -- fp32 MFMA implicit-GEMM convolutions (3x3 / 1x1, stride 1, same padding) for gfx950.
+//
+// The reference runs every convolution of the generator as ONE grouped F.conv2d over per-sample
+// weights (histoGAN/histoGAN.py:420-440) and the discriminator's as nn.Conv2d (:510-518).  Here the
+// contraction is a hand-written implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain,
+// 157.3 TFLOP/s peak) with the modulation / demodulation / bias fused as input / output scales:
+//
+//   k_conv   D[channel][pixel] = sum_{tap,k} Wt[tap][k][channel] * X[k][pixel + tap]
+//            A operand = packed weights (LDS, [tap][k][channel], channel contiguous -> conflict-free),
+//            B operand = a halo tile of the input (LDS, [k][image][row+2][col+2]); the 9 taps are 9
+//            shifted reads of the same halo tile, so the input is fetched once per k-chunk, not 9x.
+//            Output rows (channels) x columns (pixels): a lane owns one pixel, 32 consecutive lanes
+//            write 32 consecutive pixels of one channel (128 B segments).
+//            The same kernel computes the data gradient (weights packed transposed + flipped).
+//   k_wgrad  dW[tap][n][k] = sum_pixels gout[n][pixel] * X[k][pixel + tap]   (K-dim = pixels, split-K
+//            over pixel chunks into slabs, then k_wgrad_reduce sums the slabs in fixed order and
+//            writes the (N,K,kh,kw) layout).
+//   k_pack   W (Co,Ci,kh,kw) -> Wt[tap][K][N] (LDS-tiled transpose).
+//
+// Pixel tiles are NI images x TH rows x TW columns (all powers of two, chosen on the host per layer:
+// 32-wide rows for big maps, several whole images per tile for 4x4 / 8x8 maps).
+#include "hg_common.h"
+#include "../../include/hg_hist.h"
+#include "../../include/hg_conv.h"
+
+namespace {
+
+struct Geom {
+  int lTW, lTH, lNI;          // log2 of tile width / height / images per tile
+  int TWp, IMS, HALO, CHS;    // halo row length, floats per image halo, NI*IMS, LDS channel stride
+  float inv_TWp, inv_IMS, inv_HALO;
+  int tiles_x, tiles_y, groups;
+};
+
+struct ConvArgs {
+  const float *in, *wt;
+  float *out;
+  const float *iscale, *oscale, *bias;
+  int B, K, N, H, W, Kp, Np;
+  Geom g;
+};
+
+__device__ __forceinline__ int fdiv(int e, float inv) {  // floor(e / d) for 0 <= e < 2^20, d < 2^12 (see host)
+  return (int)(((float)e + 0.5f) * inv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / data-gradient kernel
+template <int WC, int WP, int TC, int TP, int TAPS, int KC>
+__global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
+  constexpr int NT = WC * WP * 64;
+  constexpr int NB = WC * TC * 32;  // channels per block
+  constexpr int MB = WP * TP * 32;  // pixels per block
+  constexpr int PAD = TAPS == 9 ? 1 : 0;
+  constexpr int WTOT = TAPS * KC * NB / 4;  // float4 per weight chunk
+  constexpr int NW = (WTOT + NT - 1) / NT;
+  constexpr int HMAX = KC * (PAD ? (MB * 9) / 4 : MB);  // >= KC*HALO for every geometry (host guarantees)
+  constexpr int NH = (HMAX + NT - 1) / NT;
+
+  extern __shared__ float smem[];
+  float *Ws = smem;                  // [TAPS][KC][NB]
+  float *Xs = smem + TAPS * KC * NB; // [KC][CHS]
+
+  const Geom &g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave % WC, wp = wave / WC;
+  const int H = a.H, W = a.W, K = a.K, N = a.N;
+
+  int pt = blockIdx.x;
+  const int tx = pt % g.tiles_x;
+  pt /= g.tiles_x;
+  const int ty = pt % g.tiles_y;
+  const int grp = pt / g.tiles_y;
+  const int x0 = tx << g.lTW, y0 = ty << g.lTH, b0 = grp << g.lNI;
+  const int n0 = blockIdx.y * NB;
+  const int TWm = (1 << g.lTW) - 1, THm = (1 << g.lTH) - 1;
+
+  // ---- staging descriptors of the halo tile (chunk-invariant)
+  int goff[NH];
+  int sidx[NH];
+  const int htot = KC * g.HALO;
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+    const int e = tid + i * NT;
+    goff[i] = -1;
+    sidx[i] = 0;
+    if (e < htot) {
+      const int kc = fdiv(e, g.inv_HALO);
+      const int r = e - kc * g.HALO;
+      const int img = fdiv(r, g.inv_IMS);
+      const int rr = r - img * g.IMS;
+      const int hy = fdiv(rr, g.inv_TWp);
+      const int hx = rr - hy * g.TWp;
+      const int gy = y0 + hy - PAD, gx = x0 + hx - PAD, b = b0 + img;
+      if (b < a.B && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+        goff[i] = ((b * K + kc) * H + gy) * W + gx;
+      sidx[i] = img * KC + kc;
+    }
+  }
+
+  // ---- operand read offsets
+  int pixoff[TP];
+#pragma unroll
+  for (int tp = 0; tp < TP; ++tp) {
+    const int p = (wp * TP + tp) * 32 + (lane & 31);
+    const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
+    pixoff[tp] = pi * g.IMS + py * g.TWp + px + (lane >> 5) * g.CHS;
+  }
+  const int aoff = (lane >> 5) * NB + wc * TC * 32 + (lane & 31);
+
+  f32x16 acc[TC][TP];
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int j = 0; j < TP; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float xr[NH];
+  f32x4 wr[NW];
+  const int nchunks = a.Kp / KC;
+  const int HW = H * W;
+
+  auto prefetch = [&](int c) __attribute__((always_inline)) {
+    const float *inb = a.in + (size_t)c * KC * HW;
+    const int krem = K - c * KC;  // channels left
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int kc = sidx[i] % KC;
+      const bool ok = goff[i] >= 0 && kc < krem;
+      float v = ok ? inb[goff[i]] : 0.f;
+      if (a.iscale != nullptr && ok) v *= a.iscale[(b0 + sidx[i] / KC) * K + c * KC + kc];
+      xr[i] = v;
+    }
+    const float *wb = a.wt + (size_t)c * KC * a.Np + n0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int e4 = tid + i * NT;
+      if (NW * NT == WTOT || e4 < WTOT) {
+        const int row = e4 / (NB / 4), c4 = e4 % (NB / 4);
+        const int t = row / KC, kc = row % KC;
+        wr[i] = *reinterpret_cast<const f32x4 *>(wb + ((size_t)t * a.Kp + kc) * a.Np + c4 * 4);
+      }
+    }
+  };
+
+  for (int c = -1; c < nchunks; ++c) {
+    if (c >= 0) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NH; ++i) {
+        const int e = tid + i * NT;
+        if (e < htot) Xs[fdiv(e, g.inv_HALO) * (g.CHS - g.HALO) + e] = xr[i];
+      }
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const int e4 = tid + i * NT;
+        if (NW * NT == WTOT || e4 < WTOT) reinterpret_cast<f32x4 *>(Ws)[e4] = wr[i];
+      }
+      __syncthreads();
+    }
+    if (c + 1 < nchunks) prefetch(c + 1);
+    if (c < 0) continue;
+
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int toff = PAD ? (t / 3) * g.TWp + (t % 3) : 0;
+#pragma unroll
+      for (int kk = 0; kk < KC / 2; ++kk) {
+        float av[TC], bv[TP];
+#pragma unroll
+        for (int i = 0; i < TC; ++i) av[i] = Ws[(t * KC + kk * 2) * NB + aoff + i * 32];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) bv[j] = Xs[pixoff[j] + toff + kk * 2 * g.CHS];
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+          for (int j = 0; j < TP; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue: D[i = channel][j = pixel]; row(i) = (r&3) + 8*(r>>2) + 4*(lane>>5), col(j) = lane&31
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    const int p = (wp * TP + j) * 32 + (lane & 31);
+    const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
+    const int gx = x0 + px, gy = y0 + py, b = b0 + pi;
+    if (b >= a.B || gy >= H || gx >= W) continue;
+    float *ob = a.out + ((size_t)b * N) * HW + gy * W + gx;
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ch = n0 + (wc * TC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (ch < N) {
+          float v = acc[i][j][r];
+          if (a.oscale) v *= a.oscale[b * N + ch];
+          if (a.bias) v += a.bias[ch];
+          ob[(size_t)ch * HW] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+struct WgradArgs {
+  const float *in, *gout;
+  float *slab;  // [splits][TAPS][Np32][Kp32]
+  const float *iscale, *gscale;
+  int B, K, N, H, W, Kp32, Np32;
+  int tiles_x, tiles_y, nchunks, splits, ktiles;
+};
+
+// compile-time pixel-chunk geometry of the weight-gradient kernel: PC pixels = NI images x TH x TW
+template <int PC, int LTW, int PAD>
+struct CGeom {
+  static constexpr int TW = 1 << LTW;
+  static constexpr int TH = (PC / TW) < TW ? (PC / TW) : TW;
+  static constexpr int NI = PC / (TW * TH);
+  static constexpr int TWp = TW + 2 * PAD, THp = TH + 2 * PAD;
+  static constexpr int IMS = TWp * THp, HALO = NI * IMS, CHS = HALO | 1;  // odd pitch: lanes vary the channel
+};
+
+// Block = WN x WK x WS waves.  A wave owns a 32(n) x 32(k) x TAPS accumulator tile (TAPS*16 VGPRs); the WS
+// waves of a tile split the pixel pairs of each chunk between them and write separate slabs.  The next
+// chunk is fetched into registers while the MFMAs of the current one run (one block per CU: the kernel
+// is allowed the full 512-register budget).
+template <int WN, int WK, int WS, int TAPS, int PC, int LTW>
+__global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
+  constexpr int NT = WN * WK * WS * 64;
+  constexpr int NBW = WN * 32;  // out channels (gout) per block
+  constexpr int KBW = WK * 32;  // in channels per block
+  constexpr int PAD = TAPS == 9 ? 1 : 0;
+  using G = CGeom<PC, LTW, PAD>;
+  constexpr int GP = PC + 1;  // odd pitch
+
+  extern __shared__ float smem[];
+  float *Gs = smem;             // [NBW][GP]
+  float *Xs = smem + NBW * GP;  // [KBW][CHS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wk = (wave / WN) % WK, ws = wave / (WN * WK);
+  const int H = a.H, W = a.W, K = a.K, N = a.N, HW = H * W;
+  const int k0 = (blockIdx.x % a.ktiles) * KBW, n0 = (blockIdx.x / a.ktiles) * NBW;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float *Ga = Gs + (wn * 32 + (lane & 31)) * GP + (lane >> 5);
+  const float *Xa = Xs + (wk * 32 + (lane & 31)) * G::CHS + (lane >> 5);
+
+  // Staging maps: a pass moves CPI whole channels; thread -> (channel slot cs, position r) is fixed, so the
+  // per-chunk address work is ONE offset per thread and each element costs one load + one LDS store.
+  constexpr int GCPI = NT / PC, NGI = (NBW + GCPI - 1) / GCPI;            // gout: PC pixels per channel
+  constexpr int HCPI = NT / G::HALO, NHI = (KBW + HCPI - 1) / HCPI;      // halo: HALO floats per channel
+  static_assert(HCPI >= 1, "halo tile wider than the block");
+  const int gcs = tid / PC, gp = tid % PC;
+  const int gpx = gp % G::TW, gpy = (gp / G::TW) % G::TH, gpi = gp / (G::TW * G::TH);
+  const int hcs = tid / G::HALO, hrr = tid % G::HALO;
+  const int himg = hrr / G::IMS, hy = (hrr % G::IMS) / G::TWp, hx = hrr % G::TWp;
+  const bool hlane = hcs < HCPI;
+
+  float gr[NGI], hr[NHI];
+  auto prefetch = [&](int chunk) __attribute__((always_inline)) {
+    int pt = chunk;
+    const int tx = pt % a.tiles_x;
+    pt /= a.tiles_x;
+    const int ty = pt % a.tiles_y;
+    const int grp = pt / a.tiles_y;
+    const int x0 = tx * G::TW, y0 = ty * G::TH, b0 = grp * G::NI;
+    {
+      const int gx = x0 + gpx, gy = y0 + gpy, b = b0 + gpi;
+      const bool ok = b < a.B && gy < H && gx < W;
+      const unsigned srow = (unsigned)(b * N + n0 + gcs);
+      const unsigned off = srow * (unsigned)HW + (unsigned)(gy * W + gx);
+#pragma unroll
+      for (int i = 0; i < NGI; ++i) {
+        float v = 0.f;
+        if (ok && n0 + gcs + i * GCPI < N && (NGI * GCPI == NBW || gcs + i * GCPI < NBW)) {
+          v = a.gout[off + (unsigned)(i * GCPI) * (unsigned)HW];
+          if (a.gscale) v *= a.gscale[srow + i * GCPI];
+        }
+        gr[i] = v;
+      }
+    }
+    {
+      const int gy = y0 + hy - PAD, gx = x0 + hx - PAD, b = b0 + himg;
+      const bool ok = hlane && b < a.B && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const unsigned srow = (unsigned)(b * K + k0 + hcs);
+      const unsigned off = srow * (unsigned)HW + (unsigned)(gy * W + gx);
+#pragma unroll
+      for (int i = 0; i < NHI; ++i) {
+        float v = 0.f;
+        if (ok && k0 + hcs + i * HCPI < K && (NHI * HCPI == KBW || hcs + i * HCPI < KBW)) {
+          v = a.in[off + (unsigned)(i * HCPI) * (unsigned)HW];
+          if (a.iscale) v *= a.iscale[srow + i * HCPI];
+        }
+        hr[i] = v;
+      }
+    }
+  };
+
+  bool have = false;
+  for (int chunk = (int)blockIdx.y - a.splits; chunk < a.nchunks; chunk += a.splits) {
+    if (have) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NGI; ++i)
+        if (NGI * GCPI == NBW || gcs + i * GCPI < NBW) Gs[(gcs + i * GCPI) * GP + gp] = gr[i];
+#pragma unroll
+      for (int i = 0; i < NHI; ++i)
+        if (hlane && (NHI * HCPI == KBW || hcs + i * HCPI < KBW)) Xs[(hcs + i * HCPI) * G::CHS + hrr] = hr[i];
+      __syncthreads();
+    }
+    if (chunk + a.splits < a.nchunks) prefetch(chunk + a.splits);
+    if (!have) {
+      have = true;
+      continue;
+    }
+
+#pragma unroll
+    for (int q = 0; q < PC / 2 / WS; ++q) {
+      const int ks = q * WS;  // this wave's pixel pair is ks + ws
+      float av;
+      float bv[TAPS];
+      if constexpr (WS == 1) {
+        const int p0 = ks * 2;
+        const int hoff = (p0 / (G::TW * G::TH)) * G::IMS + ((p0 / G::TW) % G::TH) * G::TWp + (p0 % G::TW);
+        av = Ga[p0];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) bv[t] = Xa[hoff + (PAD ? (t / 3) * G::TWp + (t % 3) : 0)];
+      } else {
+        const int p0 = (ks + ws) * 2;
+        const int hoff = (p0 / (G::TW * G::TH)) * G::IMS + ((p0 / G::TW) % G::TH) * G::TWp + (p0 % G::TW);
+        av = Ga[p0];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) bv[t] = Xa[hoff + (PAD ? (t / 3) * G::TWp + (t % 3) : 0)];
+      }
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+    }
+  }
+
+  // slab[split*WS + ws][t][n][k]: D[i = n][j = k]
+  float *sb = a.slab + ((size_t)blockIdx.y * WS + ws) * TAPS * a.Np32 * a.Kp32;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int k = k0 + wk * 32 + (lane & 31);
+      sb[((size_t)t * a.Np32 + n) * a.Kp32 + k] = acc[t][r];
+    }
+}
+
+// gw[n][k][t] = sum_s slab[s][t][n][k]
+template <int TAPS>
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ slab, float *__restrict__ gw, int N, int K,
+                                                      int Np32, int Kp32, int splits) {
+  const int k = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (k >= K) return;
+  float s[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) s[t] = 0.f;
+  const size_t sstride = (size_t)TAPS * Np32 * Kp32;
+  for (int sp = 0; sp < splits; ++sp)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) s[t] += slab[sp * sstride + ((size_t)t * Np32 + n) * Kp32 + k];
+  float *o = gw + ((size_t)n * K + k) * TAPS;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) o[t] = s[t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: W (Co,Ci,T) -> Wt[T][Kp][Np]; one block = 32 co x 32 ci x T, LDS transpose
+template <int TAPS>
+__global__ __launch_bounds__(256) void k_pack(const float *__restrict__ w, float *__restrict__ wt, int Co, int Ci, int Kp,
+                                              int Np, int mode) {
+  constexpr int RW = 32 * TAPS;  // floats per co row of the tile
+  __shared__ float tile[32][RW + 1];
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  for (int e = threadIdx.x; e < 32 * RW; e += 256) {
+    const int i = e / RW, q = e % RW;  // q = j*TAPS + t
+    const int co = co0 + i, ci = ci0 + q / TAPS;
+    tile[i][q] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci0) * TAPS + q] : 0.f;
+  }
+  __syncthreads();
+  // output element (t, a, b) with b fastest: fwd: a = ci (K), b = co (N); dgrad: a = co (K), b = ci (N)
+  for (int e = threadIdx.x; e < 32 * RW; e += 256) {
+    const int b = e & 31, a_ = (e >> 5) & 31, t = e >> 10;
+    int kk, nn;
+    float v;
+    if (mode == HG_CONV_PACK_FWD) {
+      kk = ci0 + a_; nn = co0 + b;
+      v = tile[b][a_ * TAPS + t];
+    } else {
+      kk = co0 + a_; nn = ci0 + b;
+      v = tile[a_][b * TAPS + (TAPS - 1 - t)];
+    }
+    if (kk < Kp && nn < Np) wt[((size_t)t * Kp + kk) * Np + nn] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+inline int ceil_log2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// pixel-tile geometry for MB pixels per block: TW = min(32, pow2ceil(max(W,4))), TH = min(pow2ceil(max(H,4)), MB/TW)
+Geom make_geom(int MB, int B, int H, int W, int pad, bool odd_chs) {
+  Geom g;
+  int lTW = ceil_log2(W < 4 ? 4 : W);
+  if (lTW > 5) lTW = 5;
+  const int lMB = ceil_log2(MB);
+  if (lTW > lMB - 1) lTW = lMB - 1;
+  int lTH = ceil_log2(H < 4 ? 4 : H);
+  if (lTH > lMB - lTW) lTH = lMB - lTW;
+  g.lTW = lTW; g.lTH = lTH; g.lNI = lMB - lTW - lTH;
+  const int TW = 1 << lTW, TH = 1 << lTH, NI = 1 << g.lNI;
+  g.TWp = TW + 2 * pad;
+  g.IMS = (TH + 2 * pad) * g.TWp;
+  g.HALO = NI * g.IMS;
+  g.CHS = odd_chs ? (g.HALO | 1) : g.HALO;
+  g.inv_TWp = 1.0f / (float)g.TWp;
+  g.inv_IMS = 1.0f / (float)g.IMS;
+  g.inv_HALO = 1.0f / (float)g.HALO;
+  g.tiles_x = (W + TW - 1) / TW;
+  g.tiles_y = (H + TH - 1) / TH;
+  g.groups = (B + NI - 1) / NI;
+  return g;
+}
+
+template <int WC, int WP, int TC, int TP, int TAPS, int KC>
+int launch_conv(ConvArgs a, hipStream_t st) {
+  constexpr int NB = WC * TC * 32, MB = WP * TP * 32, NT = WC * WP * 64;
+  a.g = make_geom(MB, a.B, a.H, a.W, TAPS == 9 ? 1 : 0, false);
+  const size_t lds = ((size_t)TAPS * KC * NB + (size_t)KC * a.g.CHS) * sizeof(float);
+  auto kern = k_conv<WC, WP, TC, TP, TAPS, KC>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const dim3 grid((unsigned)(a.g.tiles_x * a.g.tiles_y * a.g.groups), (unsigned)((a.N + NB - 1) / NB));
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+template <int TAPS>
+int dispatch_conv(const ConvArgs &a, hipStream_t st) {
+  const long long pix = (long long)a.B * a.H * a.W;
+  const int N = a.N;
+  // blocks each tile shape would launch; pick the largest tile that still gives >= ~2 blocks per CU
+  auto blocks = [&](int nb, int mb) { return ((N + nb - 1) / nb) * ((pix + mb - 1) / mb); };
+  if (N <= 32) return launch_conv<1, 4, 1, 2, TAPS, 8>(a, st);              // 32 ch x 256 px
+  if (N <= 64) {
+    if (blocks(64, 256) >= 384) return launch_conv<1, 4, 2, 2, TAPS, 8>(a, st);   // 64 ch x 256 px
+    return launch_conv<2, 2, 1, 1, TAPS, 16>(a, st);                        // 64 ch x 64 px
+  }
+  if (blocks(128, 128) >= 384) return launch_conv<2, 2, 2, 2, TAPS, 8>(a, st);    // 128 ch x 128 px
+  return launch_conv<2, 2, 1, 1, TAPS, 16>(a, st);                          // 64 ch x 64 px
+}
+
+struct WgradPlan {
+  int lTW, tiles_x, tiles_y, groups;
+  int WN, WK, WS;  // waves per block along n / k / pixel split
+  int nchunks, splits, ktiles, ntiles, Kp32, Np32;
+  size_t slab_bytes;
+};
+
+constexpr int WG_PC = 64;
+
+WgradPlan make_wgrad_plan(int B, int K, int N, int H, int W, int ksize) {
+  WgradPlan p;
+  int lTW = ceil_log2(W < 4 ? 4 : W);
+  if (lTW > 5) lTW = 5;
+  p.lTW = lTW;
+  const int TW = 1 << lTW, TH = (WG_PC / TW) < TW ? (WG_PC / TW) : TW, NI = WG_PC / (TW * TH);
+  p.tiles_x = (W + TW - 1) / TW;
+  p.tiles_y = (H + TH - 1) / TH;
+  p.groups = (B + NI - 1) / NI;
+  p.nchunks = p.tiles_x * p.tiles_y * p.groups;
+  p.WN = N > 32 ? 2 : 1;
+  p.WK = K > 32 ? 2 : 1;
+  p.WS = 4 / (p.WN * p.WK);
+  p.ktiles = (K + p.WK * 32 - 1) / (p.WK * 32);
+  p.ntiles = (N + p.WN * 32 - 1) / (p.WN * 32);
+  const int tiles = p.ktiles * p.ntiles;
+  int s = (512 + tiles - 1) / tiles;
+  if (s > p.nchunks) s = p.nchunks;
+  if (s < 1) s = 1;
+  p.splits = s;
+  p.Kp32 = p.ktiles * p.WK * 32;
+  p.Np32 = p.ntiles * p.WN * 32;
+  p.slab_bytes = (size_t)s * p.WS * ksize * ksize * p.Kp32 * p.Np32 * sizeof(float);
+  return p;
+}
+
+template <int WN, int WK, int WS, int TAPS, int LTW>
+int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
+  using G = CGeom<WG_PC, LTW, TAPS == 9 ? 1 : 0>;
+  const size_t lds = ((size_t)WN * 32 * (WG_PC + 1) + (size_t)WK * 32 * G::CHS) * sizeof(float);
+  auto kern = k_wgrad<WN, WK, WS, TAPS, WG_PC, LTW>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.ktiles * p.ntiles), (unsigned)p.splits), dim3(WN * WK * WS * 64), lds, st, a);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+template <int TAPS, int LTW>
+int launch_wgrad_g(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
+  if (p.WN == 2 && p.WK == 2) return launch_wgrad_k<2, 2, 1, TAPS, LTW>(a, p, st);
+  if (p.WN == 2) return launch_wgrad_k<2, 1, 2, TAPS, LTW>(a, p, st);
+  if (p.WK == 2) return launch_wgrad_k<1, 2, 2, TAPS, LTW>(a, p, st);
+  return launch_wgrad_k<1, 1, 4, TAPS, LTW>(a, p, st);
+}
+
+template <int TAPS>
+int launch_wgrad(WgradArgs a, const WgradPlan &p, float *gw, hipStream_t st) {
+  a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
+  a.nchunks = p.nchunks; a.splits = p.splits; a.ktiles = p.ktiles; a.Kp32 = p.Kp32; a.Np32 = p.Np32;
+  int rc;
+  switch (p.lTW) {
+    case 2: rc = launch_wgrad_g<TAPS, 2>(a, p, st); break;
+    case 3: rc = launch_wgrad_g<TAPS, 3>(a, p, st); break;
+    case 4: rc = launch_wgrad_g<TAPS, 4>(a, p, st); break;
+    default: rc = launch_wgrad_g<TAPS, 5>(a, p, st); break;
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_wgrad_reduce<TAPS>, dim3((unsigned)((a.K + 255) / 256), (unsigned)a.N), dim3(256), 0, st, a.slab, gw,
+                     a.N, a.K, p.Np32, p.Kp32, p.splits * p.WS);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+inline bool conv_args_ok(int B, int K, int N, int H, int W, int ksize) {
+  if (B <= 0 || K <= 0 || N <= 0 || H <= 0 || W <= 0) return false;
+  if (ksize != 1 && ksize != 3) return false;
+  return true;
+}
+inline bool fits_i32(int B, int K, int N, int H, int W) {
+  const long long lim = 0x7fffffffLL;
+  return (long long)B * K * H * W < lim && (long long)B * N * H * W < lim;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t hg_conv_packed_elems(int32_t Co, int32_t Ci, int32_t ksize, int32_t mode) {
+  if (Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3)) return 0;
+  const int K = mode == HG_CONV_PACK_FWD ? Ci : Co, N = mode == HG_CONV_PACK_FWD ? Co : Ci;
+  return (size_t)ksize * ksize * round_up(K, 16) * round_up(N, 128);
+}
+
+int hg_conv_pack_weights(const float *w, float *wt, int32_t Co, int32_t Ci, int32_t ksize, int32_t mode, void *stream) {
+  if (!w || !wt || Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3)) return HG_EINVAL;
+  if (mode != HG_CONV_PACK_FWD && mode != HG_CONV_PACK_DGRAD) return HG_EINVAL;
+  const int K = mode == HG_CONV_PACK_FWD ? Ci : Co, N = mode == HG_CONV_PACK_FWD ? Co : Ci;
+  const int Kp = round_up(K, 16), Np = round_up(N, 128);
+  // the grid covers the padded extent so that the padding is written (as zeros)
+  const int CiP = mode == HG_CONV_PACK_FWD ? Kp : Np, CoP = mode == HG_CONV_PACK_FWD ? Np : Kp;
+  const dim3 grid((unsigned)((CiP + 31) / 32), (unsigned)((CoP + 31) / 32));
+  hipStream_t st = (hipStream_t)stream;
+  if (ksize == 3)
+    hipLaunchKernelGGL(k_pack<9>, grid, dim3(256), 0, st, w, wt, Co, Ci, Kp, Np, mode);
+  else
+    hipLaunchKernelGGL(k_pack<1>, grid, dim3(256), 0, st, w, wt, Co, Ci, Kp, Np, mode);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+int hg_conv2d_same(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
+                   const float *bias, int32_t B, int32_t K, int32_t N, int32_t H, int32_t W, int32_t ksize,
+                   void *stream) {
+  if (!in || !wt || !out || !conv_args_ok(B, K, N, H, W, ksize)) return HG_EINVAL;
+  if (!fits_i32(B, K, N, H, W)) return HG_EUNSUPPORTED;
+  ConvArgs a;
+  a.in = in; a.wt = wt; a.out = out; a.iscale = iscale; a.oscale = oscale; a.bias = bias;
+  a.B = B; a.K = K; a.N = N; a.H = H; a.W = W;
+  a.Kp = round_up(K, 16); a.Np = round_up(N, 128);
+  return ksize == 3 ? dispatch_conv<9>(a, (hipStream_t)stream) : dispatch_conv<1>(a, (hipStream_t)stream);
+}
+
+size_t hg_conv2d_wgrad_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t H, int32_t W, int32_t ksize) {
+  if (!conv_args_ok(B, K, N, H, W, ksize)) return 0;
+  return make_wgrad_plan(B, K, N, H, W, ksize).slab_bytes;
+}
+
+int hg_conv2d_wgrad(const float *in, const float *gout, float *gw, const float *iscale, const float *gscale, int32_t B,
+                    int32_t K, int32_t N, int32_t H, int32_t W, int32_t ksize, void *workspace, size_t workspace_bytes,
+                    void *stream) {
+  if (!in || !gout || !gw || !workspace || !conv_args_ok(B, K, N, H, W, ksize)) return HG_EINVAL;
+  if (!fits_i32(B, K, N, H, W)) return HG_EUNSUPPORTED;
+  const WgradPlan p = make_wgrad_plan(B, K, N, H, W, ksize);
+  if (workspace_bytes < p.slab_bytes) return HG_EWORKSPACE;
+  WgradArgs a;
+  a.in = in; a.gout = gout; a.slab = (float *)workspace; a.iscale = iscale; a.gscale = gscale;
+  a.B = B; a.K = K; a.N = N; a.H = H; a.W = W;
+  return ksize == 3 ? launch_wgrad<9>(a, p, gw, (hipStream_t)stream) : launch_wgrad<1>(a, p, gw, (hipStream_t)stream);
+}
+
+}  // extern "C"

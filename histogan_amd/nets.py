@@ -5,7 +5,8 @@ execution plan:
 * Conv2DMod (reference :404-440) runs in activation-modulation form
       out = d[b,o] * conv(up?(x) * (s+1), W),   d = rsqrt(((s+1)^2) @ sum_k W^2 + 1e-8)
   -- prologue/epilogue are the fused HIP kernels of histogan_amd/csrc/hg_nets.hip, the dense contraction
-  uses the SHARED weight (no B x O x I x k x k per-sample weights, no grouped conv).
+  is the hand-written fp32-MFMA implicit GEMM of histogan_amd/csrc/hg_conv.hip on the SHARED weight
+  (no B x O x I x k x k per-sample weights, no grouped conv, no MIOpen).
 * GeneratorBlock (reference :443-502) fuses the bilinear x2 upsample into conv1's prologue and the
   noise add + LeakyReLU(0.2) (+ demodulation) into each conv's epilogue.
 * Discriminator / vectorizers are plain PyTorch-ROCm modules (MIOpen / rocBLAS): the discriminator must
@@ -18,6 +19,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
+from .conv import conv2d_same
 
 EPS = 1e-8  # histoGAN/histoGAN.py:53
 
@@ -67,8 +69,9 @@ class Conv2DMod(nn.Module):
         if self.stride != 1:
             raise NotImplementedError('Conv2DMod: stride != 1 is not used by HistoGAN and not implemented')
         xm = ops.modulate(x, y, upsample)
-        pad = self._get_same_padding(xm.shape[2], self.kernel, self.dilation, self.stride)
-        return F.conv2d(xm, self.weight, padding=pad, dilation=self.dilation)
+        if self.dilation == 1 and self.kernel in (1, 3):
+            return conv2d_same(xm, self.weight)      # fp32-MFMA implicit GEMM (include/hg_conv.h)
+        raise NotImplementedError('Conv2DMod: only 1x1 / 3x3, dilation 1 (all HistoGAN uses) is implemented')
 
     def forward(self, x, y):
         c = self.contract(x, y)
