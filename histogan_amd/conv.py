@@ -1,11 +1,15 @@
 """Dense contraction of the HistoGAN networks on the hand-written fp32-MFMA kernels of include/hg_conv.h.
 
-`conv2d_same(x, w, bias=None)` == `F.conv2d(x, w, bias, padding=k//2)` for k in {1, 3}, stride 1 -- the
-contraction inside Conv2DMod.forward (histoGAN/histoGAN.py:431-439, executed with the shared weight on
-modulated activations) and the discriminator's stride-1 convolutions (:510-515).  Output, data gradient and
-weight gradient are three launches of the implicit-GEMM kernels (k_conv with forward-/dgrad-packed
-weights, k_wgrad); first-order differentiable.
+`conv2d(x, w, bias=None, stride=1)` == `F.conv2d(x, w, bias, stride=stride, padding=k//2)` for k in {1, 3}
+(stride 2 only for k = 3) -- the contraction inside Conv2DMod.forward (histoGAN/histoGAN.py:431-439, executed
+with the shared weight on modulated activations) and every convolution of the discriminator (:510-518).
+
+A convolution is bilinear in (x, w), so its output, data gradient and weight gradient are closed under
+differentiation.  The three autograd Functions below call each other in their backward passes, which makes
+the op differentiable to any order with only the three kernels (k_conv forward/dgrad, k_wgrad) -- the
+gradient penalty (histoGAN/histoGAN.py:156-163) needs the second order.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -13,6 +17,20 @@ import torch
 from ._lib import check, lib
 
 PACK_FWD, PACK_DGRAD = 0, 1
+_skip_wgrad = False
+
+
+@contextlib.contextmanager
+def input_grads_only():
+    """Inside this context the backward of conv2d does not compute weight / bias gradients (they come back as
+    None).  For `torch.autograd.grad(out, inputs=images, create_graph=True)` (the gradient penalty), where the
+    autograd engine would otherwise make every conv node produce a weight gradient nobody asked for."""
+    global _skip_wgrad
+    old, _skip_wgrad = _skip_wgrad, True
+    try:
+        yield
+    finally:
+        _skip_wgrad = old
 
 
 def _st(t):
@@ -20,6 +38,7 @@ def _st(t):
 
 
 def _f32c(t):
+    t = t.detach()
     t = t if t.dtype == torch.float32 else t.float()
     return t if t.is_contiguous() else t.contiguous()
 
@@ -28,8 +47,57 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _out_size(n, stride):
+    return (n - 1) // stride + 1
+
+
+def _check_args(x, w, stride):
+    if not x.is_cuda:
+        raise RuntimeError(f'conv2d: tensor on {x.device}; the MI355X-native path has no CPU implementation')
+    Co, Ci, k, k2 = w.shape
+    if k != k2 or k not in (1, 3) or stride not in (1, 2) or (stride == 2 and k != 3):
+        raise ValueError(f'conv2d: weight {tuple(w.shape)} stride {stride} not supported (1x1 / 3x3 stride 1, 3x3 stride 2)')
+
+
+# Packed-weight cache.  Only tensors registered with `enable_pack_cache(params)` are cached (keyed by their
+# address): the Trainer registers its convolution weights, which live in one flat buffer for the life of the
+# model and only change through DiffGrad.step / ema_update / load_state_dict -- the first two update through
+# raw pointers (no version counter moves) and therefore call `weights_changed()`.  Everything else (plain
+# torch users, the temporaries of a double backward) is packed on every call.
+_cacheable = set()
+_cache = {}
+_generation = 0
+
+
+def enable_pack_cache(params=None):
+    """Register convolution weights (4-D tensors among `params`) for packed-weight caching; None switches it off."""
+    _cache.clear()
+    _cacheable.clear()
+    for p in (params or ()):
+        if p.dim() == 4:
+            _cacheable.add((p.data_ptr(), tuple(p.shape)))
+
+
+def weights_changed():
+    """Invalidate every cached packed weight (called by the fused optimizer / EMA kernels)."""
+    global _generation
+    _generation += 1
+
+
 def pack_weights(w, mode):
-    """(Co,Ci,k,k) -> the packed operand Wt[k*k][Kp][Np] of hg_conv2d_same (mode PACK_FWD / PACK_DGRAD)."""
+    """(Co,Ci,k,k) -> the packed operand Wt[k*k][Kp][Np] of hg_conv2d_fwd / hg_conv2d_dgrad."""
+    key = (w.data_ptr(), tuple(w.shape))
+    if key in _cacheable:
+        hit = _cache.get((key, mode))
+        if hit is not None and hit[0] == (_generation, w._version):
+            return hit[1]
+        wt = _pack_weights(w, mode)
+        _cache[(key, mode)] = ((_generation, w._version), wt)
+        return wt
+    return _pack_weights(w, mode)
+
+
+def _pack_weights(w, mode):
     Co, Ci, k, _ = w.shape
     n = lib.hg_conv_packed_elems(Co, Ci, k, mode)
     if n == 0:
@@ -40,59 +108,114 @@ def pack_weights(w, mode):
     return wt
 
 
-def conv_packed(x, wt, N, ksize, iscale=None, oscale=None, bias=None):
+def conv_fwd_packed(x, wt, N, ksize, stride=1, iscale=None, oscale=None, bias=None):
     """out[b,n] = oscale[b,n] * sum_k conv(iscale[b,k] * x[b,k], Wt[.,k,n]) + bias[n]   (x: (B,K,H,W) contiguous)."""
     B, K, H, W = x.shape
     with torch.cuda.device(x.device):
-        out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
-        check(lib.hg_conv2d_same(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(iscale), _ptr(oscale), _ptr(bias),
-                                 B, K, N, H, W, ksize, _st(x)), 'hg_conv2d_same')
+        out = torch.empty((B, N, _out_size(H, stride), _out_size(W, stride)), dtype=torch.float32, device=x.device)
+        check(lib.hg_conv2d_fwd(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(iscale), _ptr(oscale), _ptr(bias),
+                                B, K, N, H, W, ksize, stride, _st(x)), 'hg_conv2d_fwd')
     return out
 
 
-def conv_wgrad(x, gout, ksize, iscale=None, gscale=None):
-    """gw[n,k,dy,dx] = sum_{b,y,x} gscale[b,n] gout[b,n,y,x] * iscale[b,k] x[b,k,y+dy-p,x+dx-p]."""
+def conv_dgrad_packed(g, wt, N, H, W, ksize, stride=1, iscale=None, oscale=None):
+    """Data gradient: g (B,K,Ho,Wo) -> (B,N,H,W); wt packed with PACK_DGRAD."""
+    B, K = g.shape[:2]
+    with torch.cuda.device(g.device):
+        gin = torch.empty((B, N, H, W), dtype=torch.float32, device=g.device)
+        check(lib.hg_conv2d_dgrad(g.data_ptr(), wt.data_ptr(), gin.data_ptr(), _ptr(iscale), _ptr(oscale),
+                                  B, K, N, H, W, ksize, stride, _st(g)), 'hg_conv2d_dgrad')
+    return gin
+
+
+def conv_wgrad(x, gout, ksize, stride=1, iscale=None, gscale=None):
+    """gw[n,k,dy,dx] = sum_{b,y,x} gscale[b,n] gout[b,n,y,x] * iscale[b,k] x[b,k,y*s+dy-p,x*s+dx-p]."""
     B, K, H, W = x.shape
     N = gout.shape[1]
     with torch.cuda.device(x.device):
-        nbytes = lib.hg_conv2d_wgrad_workspace_bytes(B, K, N, H, W, ksize)
+        nbytes = lib.hg_conv2d_wgrad_workspace_bytes(B, K, N, H, W, ksize, stride)
         ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=x.device)
         gw = torch.empty((N, K, ksize, ksize), dtype=torch.float32, device=x.device)
         check(lib.hg_conv2d_wgrad(x.data_ptr(), gout.data_ptr(), gw.data_ptr(), _ptr(iscale), _ptr(gscale),
-                                  B, K, N, H, W, ksize, ws.data_ptr(), ws.numel(), _st(x)), 'hg_conv2d_wgrad')
+                                  B, K, N, H, W, ksize, stride, ws.data_ptr(), ws.numel(), _st(x)), 'hg_conv2d_wgrad')
     return gw
 
 
-class _Conv2dSame(torch.autograd.Function):
+class _Conv(torch.autograd.Function):
+    """y = conv(x, w) + bias."""
+
     @staticmethod
-    def forward(ctx, x, w, bias):
-        if not x.is_cuda:
-            raise RuntimeError(f'conv2d_same: tensor on {x.device}; the MI355X-native path has no CPU implementation')
-        x, w = _f32c(x.detach()), _f32c(w.detach())
-        b = None if bias is None else _f32c(bias.detach())
-        Co, Ci, k, k2 = w.shape
-        if k != k2 or k not in (1, 3) or x.shape[1] != Ci:
-            raise ValueError(f'conv2d_same: x {tuple(x.shape)} / w {tuple(w.shape)} not supported (1x1 / 3x3, stride 1)')
-        out = conv_packed(x, pack_weights(w, PACK_FWD), Co, k, bias=b)
+    def forward(ctx, x, w, bias, stride):
+        _check_args(x, w, stride)
+        if x.shape[1] != w.shape[1]:
+            raise ValueError(f'conv2d: x {tuple(x.shape)} does not match w {tuple(w.shape)}')
         ctx.save_for_backward(x, w)
-        ctx.has_bias = bias is not None
-        return out
+        ctx.stride, ctx.has_bias = stride, bias is not None
+        xc, wc = _f32c(x), _f32c(w)
+        return conv_fwd_packed(xc, pack_weights(wc, PACK_FWD), w.shape[0], w.shape[2], stride,
+                               bias=None if bias is None else _f32c(bias))
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
-        g = _f32c(g.detach())
-        Co, Ci, k, _ = w.shape
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = conv_packed(g, pack_weights(w, PACK_DGRAD), Ci, k)
+            gx = _ConvDgrad.apply(g, w, x.shape[2], x.shape[3], ctx.stride)
+        if not _skip_wgrad:
+            if ctx.needs_input_grad[1]:
+                gw = _ConvWgrad.apply(g, x, w.shape[2], ctx.stride)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = g.sum(dim=(0, 2, 3))
+        return gx, gw, gb, None
+
+
+class _ConvDgrad(torch.autograd.Function):
+    """gx = conv^T(g, w): the data gradient of _Conv; bilinear in (g, w)."""
+
+    @staticmethod
+    def forward(ctx, g, w, H, W, stride):
+        _check_args(g, w, stride)
+        ctx.save_for_backward(g, w)
+        ctx.stride = stride
+        return conv_dgrad_packed(_f32c(g), pack_weights(_f32c(w), PACK_DGRAD), w.shape[1], H, W, w.shape[2], stride)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        g, w = ctx.saved_tensors
+        gg = gw = None
+        if ctx.needs_input_grad[0]:
+            gg = _Conv.apply(ggx, w, None, ctx.stride)
+        if ctx.needs_input_grad[1] and not _skip_wgrad:
+            gw = _ConvWgrad.apply(g, ggx, w.shape[2], ctx.stride)
+        return gg, gw, None, None, None
+
+
+class _ConvWgrad(torch.autograd.Function):
+    """gw = sum_pixels g (x) x: the weight gradient of _Conv; bilinear in (g, x)."""
+
+    @staticmethod
+    def forward(ctx, g, x, ksize, stride):
+        if not x.is_cuda:
+            raise RuntimeError('conv2d: no CPU implementation')
+        ctx.save_for_backward(g, x)
+        ctx.stride = stride
+        return conv_wgrad(_f32c(x), _f32c(g), ksize, stride)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        g, x = ctx.saved_tensors
+        gg = gx = None
+        if ctx.needs_input_grad[0]:
+            gg = _Conv.apply(x, ggw, None, ctx.stride)
         if ctx.needs_input_grad[1]:
-            gw = conv_wgrad(x, g, k)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum(dim=(0, 2, 3))
-        return gx, gw, gb
+            gx = _ConvDgrad.apply(g, ggw, x.shape[2], x.shape[3], ctx.stride)
+        return gg, gx, None, None
+
+
+def conv2d(x, w, bias=None, stride=1):
+    """F.conv2d(x, w, bias, stride=stride, padding=k//2) for k in {1,3} on the MFMA implicit-GEMM kernels."""
+    return _Conv.apply(x, w, bias, stride)
 
 
 def conv2d_same(x, w, bias=None):
-    """F.conv2d(x, w, bias, stride=1, padding=k//2) for k in {1,3} on the MFMA implicit-GEMM kernels."""
-    return _Conv2dSame.apply(x, w, bias)
+    return _Conv.apply(x, w, bias, 1)

@@ -1,18 +1,20 @@
-// hg_conv.hip -- fp32 MFMA implicit-GEMM convolutions (3x3 / 1x1, stride 1, same padding) for gfx950.
+// hg_conv.hip -- fp32 MFMA implicit-GEMM convolutions (3x3 / 1x1, stride 1 or 2, padding k/2) for gfx950.
 //
 // The reference runs every convolution of the generator as ONE grouped F.conv2d over per-sample
 // weights (histoGAN/histoGAN.py:420-440) and the discriminator's as nn.Conv2d (:510-518).  Here the
 // contraction is a hand-written implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain,
 // 157.3 TFLOP/s peak) with the modulation / demodulation / bias fused as input / output scales:
 //
-//   k_conv   D[channel][pixel] = sum_{tap,k} Wt[tap][k][channel] * X[k][pixel + tap]
+//   k_conv   D[channel][pixel] = sum_{tap,k} Wt[tap][k][channel] * X[k][pixel*IS + tap]
 //            A operand = packed weights (LDS, [tap][k][channel], channel contiguous -> conflict-free),
-//            B operand = a halo tile of the input (LDS, [k][image][row+2][col+2]); the 9 taps are 9
-//            shifted reads of the same halo tile, so the input is fetched once per k-chunk, not 9x.
+//            B operand = a halo tile of the input (LDS, [k][image][rows][cols]); the taps are shifted
+//            reads of the same halo tile, so the input is fetched once per k-chunk, not 9x.
 //            Output rows (channels) x columns (pixels): a lane owns one pixel, 32 consecutive lanes
 //            write 32 consecutive pixels of one channel (128 B segments).
-//            The same kernel computes the data gradient (weights packed transposed + flipped).
-//   k_wgrad  dW[tap][n][k] = sum_pixels gout[n][pixel] * X[k][pixel + tap]   (K-dim = pixels, split-K
+//            The same kernel computes the data gradient: stride 1 = the forward kernel on transposed +
+//            flipped weights; stride 2 = four launches, one per output parity class, each with the
+//            1/2/2/4 taps that reach that class (no multiplications by inserted zeros).
+//   k_wgrad  dW[tap][n][k] = sum_pixels gout[n][pixel] * X[k][pixel*IS + tap]   (K-dim = pixels, split-K
 //            over pixel chunks into slabs, then k_wgrad_reduce sums the slabs in fixed order and
 //            writes the (N,K,kh,kw) layout).
 //   k_pack   W (Co,Ci,kh,kw) -> Wt[tap][K][N] (LDS-tiled transpose).
@@ -30,13 +32,20 @@ struct Geom {
   int TWp, IMS, HALO, CHS;    // halo row length, floats per image halo, NI*IMS, LDS channel stride
   float inv_TWp, inv_IMS, inv_HALO;
   int tiles_x, tiles_y, groups;
+  int lo_y, lo_x;             // input coordinate of halo element (0,0) = tile_origin*IS + lo
 };
 
 struct ConvArgs {
   const float *in, *wt;
   float *out;
   const float *iscale, *oscale, *bias;
-  int B, K, N, H, W, Kp, Np;
+  int B, K, N, Kp, Np;
+  int Hi, Wi;      // input image
+  int Ho, Wo;      // output image
+  int Hc, Wc;      // compute grid: pixel (y,x) reads input (y*IS + dy, x*IS + dx), writes (y*os + oy, x*os + ox)
+  int os, oy, ox;
+  int toff[9];     // LDS offset of tap t inside the halo tile
+  int ntx, wrow0, wrow_dy, wrow_dx;  // packed-weight row of tap t = wrow0 + (t / ntx)*wrow_dy + (t % ntx)*wrow_dx
   Geom g;
 };
 
@@ -45,16 +54,20 @@ __device__ __forceinline__ int fdiv(int e, float inv) {  // floor(e / d) for 0 <
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward / data-gradient kernel
-template <int WC, int WP, int TC, int TP, int TAPS, int KC>
+// output / data-gradient kernel
+template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM>
 __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
   constexpr int NT = WC * WP * 64;
   constexpr int NB = WC * TC * 32;  // channels per block
   constexpr int MB = WP * TP * 32;  // pixels per block
-  constexpr int PAD = TAPS == 9 ? 1 : 0;
-  constexpr int WTOT = TAPS * KC * NB / 4;  // float4 per weight chunk
+  constexpr int WPT = KC * NB / 4;  // float4 per tap of a weight chunk
+  constexpr int WTOT = TAPS * WPT;
   constexpr int NW = (WTOT + NT - 1) / NT;
-  constexpr int HMAX = KC * (PAD ? (MB * 9) / 4 : MB);  // >= KC*HALO for every geometry (host guarantees)
+  // Upper bound (in 1/16 per pixel) of the halo size over the geometries the host builds for this tile shape:
+  // 256-pixel tiles are only used with rows >= 16 wide (32x8 / 16x16: <= 1.33), 128-pixel tiles with rows >= 8
+  // wide (<= 1.6), 64-pixel tiles with anything down to 4x4 (2.25) or, with SM, 2x2 maps (4.0); stride 2: 5.08.
+  constexpr int R16 = IS == 2 ? 83 : (TAPS == 1 ? 16 : (SM ? 64 : (MB == 256 ? 22 : (MB == 128 ? 26 : 36))));
+  constexpr int HMAX = KC * MB * R16 / 16;
   constexpr int NH = (HMAX + NT - 1) / NT;
 
   extern __shared__ float smem[];
@@ -64,7 +77,7 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
   const Geom &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wc = wave % WC, wp = wave / WC;
-  const int H = a.H, W = a.W, K = a.K, N = a.N;
+  const int Hi = a.Hi, Wi = a.Wi, K = a.K, N = a.N;
 
   int pt = blockIdx.x;
   const int tx = pt % g.tiles_x;
@@ -77,13 +90,11 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
 
   // ---- staging descriptors of the halo tile (chunk-invariant)
   int goff[NH];
-  int sidx[NH];
   const int htot = KC * g.HALO;
 #pragma unroll
   for (int i = 0; i < NH; ++i) {
     const int e = tid + i * NT;
     goff[i] = -1;
-    sidx[i] = 0;
     if (e < htot) {
       const int kc = fdiv(e, g.inv_HALO);
       const int r = e - kc * g.HALO;
@@ -91,11 +102,17 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
       const int rr = r - img * g.IMS;
       const int hy = fdiv(rr, g.inv_TWp);
       const int hx = rr - hy * g.TWp;
-      const int gy = y0 + hy - PAD, gx = x0 + hx - PAD, b = b0 + img;
-      if (b < a.B && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-        goff[i] = ((b * K + kc) * H + gy) * W + gx;
-      sidx[i] = img * KC + kc;
+      const int gy = y0 * IS + g.lo_y + hy, gx = x0 * IS + g.lo_x + hx, b = b0 + img;
+      if (b < a.B && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi)
+        goff[i] = ((b * K + kc) * Hi + gy) * Wi + gx;
     }
+  }
+  // weight staging: element id = tid + i*NT -> (tap, float4 in the tap's [KC][NB] slice); the packed row of the tap
+  int wrow[NW];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int t = (tid + i * NT) / WPT;
+    wrow[i] = t < TAPS ? a.wrow0 + (t / a.ntx) * a.wrow_dy + (t % a.ntx) * a.wrow_dx : 0;
   }
 
   // ---- operand read offsets
@@ -104,7 +121,7 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
   for (int tp = 0; tp < TP; ++tp) {
     const int p = (wp * TP + tp) * 32 + (lane & 31);
     const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
-    pixoff[tp] = pi * g.IMS + py * g.TWp + px + (lane >> 5) * g.CHS;
+    pixoff[tp] = pi * g.IMS + py * IS * g.TWp + px * IS + (lane >> 5) * g.CHS;
   }
   const int aoff = (lane >> 5) * NB + wc * TC * 32 + (lane & 31);
 
@@ -118,28 +135,33 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
 
   float xr[NH];
   f32x4 wr[NW];
-  const int nchunks = a.Kp / KC;
-  const int HW = H * W;
+  const int nchunks = (K + KC - 1) / KC;
+  const int HWi = Hi * Wi;
 
   auto prefetch = [&](int c) __attribute__((always_inline)) {
-    const float *inb = a.in + (size_t)c * KC * HW;
+    const float *inb = a.in + (size_t)c * KC * HWi;
     const int krem = K - c * KC;  // channels left
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
-      const int kc = sidx[i] % KC;
-      const bool ok = goff[i] >= 0 && kc < krem;
+      bool ok = goff[i] >= 0;
+      if (krem < KC) ok = ok && fdiv(tid + i * NT, g.inv_HALO) < krem;   // last, partial chunk only
       float v = ok ? inb[goff[i]] : 0.f;
-      if (a.iscale != nullptr && ok) v *= a.iscale[(b0 + sidx[i] / KC) * K + c * KC + kc];
+      if (a.iscale != nullptr && ok) {
+        const int e = tid + i * NT;
+        const int kc = fdiv(e, g.inv_HALO);
+        const int img = fdiv(e - kc * g.HALO, g.inv_IMS);
+        v *= a.iscale[(b0 + img) * K + c * KC + kc];
+      }
       xr[i] = v;
     }
     const float *wb = a.wt + (size_t)c * KC * a.Np + n0;
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
-      const int e4 = tid + i * NT;
-      if (NW * NT == WTOT || e4 < WTOT) {
-        const int row = e4 / (NB / 4), c4 = e4 % (NB / 4);
-        const int t = row / KC, kc = row % KC;
-        wr[i] = *reinterpret_cast<const f32x4 *>(wb + ((size_t)t * a.Kp + kc) * a.Np + c4 * 4);
+      const int id = tid + i * NT;
+      if (NW * NT == WTOT || id < WTOT) {
+        const int e4 = id % WPT;
+        const int kc = e4 / (NB / 4), c4 = e4 % (NB / 4);
+        wr[i] = *reinterpret_cast<const f32x4 *>(wb + ((size_t)wrow[i] + kc) * a.Np + c4 * 4);
       }
     }
   };
@@ -154,8 +176,8 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
-        const int e4 = tid + i * NT;
-        if (NW * NT == WTOT || e4 < WTOT) reinterpret_cast<f32x4 *>(Ws)[e4] = wr[i];
+        const int id = tid + i * NT;
+        if (NW * NT == WTOT || id < WTOT) reinterpret_cast<f32x4 *>(Ws)[id] = wr[i];
       }
       __syncthreads();
     }
@@ -164,7 +186,7 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
 
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
-      const int toff = PAD ? (t / 3) * g.TWp + (t % 3) : 0;
+      const int toff = a.toff[t];
 #pragma unroll
       for (int kk = 0; kk < KC / 2; ++kk) {
         float av[TC], bv[TP];
@@ -182,13 +204,14 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
   }
 
   // ---- epilogue: D[i = channel][j = pixel]; row(i) = (r&3) + 8*(r>>2) + 4*(lane>>5), col(j) = lane&31
+  const int HWo = a.Ho * a.Wo;
 #pragma unroll
   for (int j = 0; j < TP; ++j) {
     const int p = (wp * TP + j) * 32 + (lane & 31);
     const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
-    const int gx = x0 + px, gy = y0 + py, b = b0 + pi;
-    if (b >= a.B || gy >= H || gx >= W) continue;
-    float *ob = a.out + ((size_t)b * N) * HW + gy * W + gx;
+    const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
+    if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
+    float *ob = a.out + ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
 #pragma unroll
@@ -198,7 +221,7 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
           float v = acc[i][j][r];
           if (a.oscale) v *= a.oscale[b * N + ch];
           if (a.bias) v += a.bias[ch];
-          ob[(size_t)ch * HW] = v;
+          ob[(size_t)ch * HWo] = v;
         }
       }
     }
@@ -209,33 +232,34 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
 // weight gradient
 struct WgradArgs {
   const float *in, *gout;
-  float *slab;  // [splits][TAPS][Np32][Kp32]
+  float *slab;  // [splits*WS][TAPS][Np32][Kp32]
   const float *iscale, *gscale;
-  int B, K, N, H, W, Kp32, Np32;
+  int B, K, N, Hi, Wi, Ho, Wo, Kp32, Np32;
   int tiles_x, tiles_y, nchunks, splits, ktiles;
+  float *gw;  // non-NULL: a single slab would be written -> store straight into gw (N,K,taps) instead
 };
 
-// compile-time pixel-chunk geometry of the weight-gradient kernel: PC pixels = NI images x TH x TW
-template <int PC, int LTW, int PAD>
+// compile-time pixel-chunk geometry of the weight-gradient kernel: PC (output) pixels = NI images x TH x TW
+template <int PC, int LTW, int PAD, int IS>
 struct CGeom {
   static constexpr int TW = 1 << LTW;
   static constexpr int TH = (PC / TW) < TW ? (PC / TW) : TW;
   static constexpr int NI = PC / (TW * TH);
-  static constexpr int TWp = TW + 2 * PAD, THp = TH + 2 * PAD;
+  static constexpr int TWp = (TW - 1) * IS + 1 + 2 * PAD, THp = (TH - 1) * IS + 1 + 2 * PAD;
   static constexpr int IMS = TWp * THp, HALO = NI * IMS, CHS = HALO | 1;  // odd pitch: lanes vary the channel
 };
 
-// Block = WN x WK x WS waves.  A wave owns a 32(n) x 32(k) x TAPS accumulator tile (TAPS*16 VGPRs); the WS
+// Block = WN x WK x WS waves.  A wave owns a 32(n) x 32(k) x TAPS accumulator tile (TAPS*16 registers); the WS
 // waves of a tile split the pixel pairs of each chunk between them and write separate slabs.  The next
-// chunk is fetched into registers while the MFMAs of the current one run (one block per CU: the kernel
-// is allowed the full 512-register budget).
-template <int WN, int WK, int WS, int TAPS, int PC, int LTW>
+// chunk is fetched into registers while the MFMAs of the current one run (the kernel is allowed the full
+// 512-register budget: accumulators in AGPRs, staging in VGPRs).
+template <int WN, int WK, int WS, int TAPS, int PC, int LTW, int IS>
 __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
   constexpr int NT = WN * WK * WS * 64;
   constexpr int NBW = WN * 32;  // out channels (gout) per block
   constexpr int KBW = WK * 32;  // in channels per block
   constexpr int PAD = TAPS == 9 ? 1 : 0;
-  using G = CGeom<PC, LTW, PAD>;
+  using G = CGeom<PC, LTW, PAD, IS>;
   constexpr int GP = PC + 1;  // odd pitch
 
   extern __shared__ float smem[];
@@ -244,7 +268,8 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wk = (wave / WN) % WK, ws = wave / (WN * WK);
-  const int H = a.H, W = a.W, K = a.K, N = a.N, HW = H * W;
+  const int Hi = a.Hi, Wi = a.Wi, Ho = a.Ho, Wo = a.Wo, K = a.K, N = a.N;
+  const int HWi = Hi * Wi, HWo = Ho * Wo;
   const int k0 = (blockIdx.x % a.ktiles) * KBW, n0 = (blockIdx.x / a.ktiles) * NBW;
 
   f32x16 acc[TAPS];
@@ -254,7 +279,7 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
   const float *Ga = Gs + (wn * 32 + (lane & 31)) * GP + (lane >> 5);
-  const float *Xa = Xs + (wk * 32 + (lane & 31)) * G::CHS + (lane >> 5);
+  const float *Xa = Xs + (wk * 32 + (lane & 31)) * G::CHS + (lane >> 5) * IS;
 
   // Staging maps: a pass moves CPI whole channels; thread -> (channel slot cs, position r) is fixed, so the
   // per-chunk address work is ONE offset per thread and each element costs one load + one LDS store.
@@ -277,29 +302,29 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
     const int x0 = tx * G::TW, y0 = ty * G::TH, b0 = grp * G::NI;
     {
       const int gx = x0 + gpx, gy = y0 + gpy, b = b0 + gpi;
-      const bool ok = b < a.B && gy < H && gx < W;
+      const bool ok = b < a.B && gy < Ho && gx < Wo;
       const unsigned srow = (unsigned)(b * N + n0 + gcs);
-      const unsigned off = srow * (unsigned)HW + (unsigned)(gy * W + gx);
+      const unsigned off = srow * (unsigned)HWo + (unsigned)(gy * Wo + gx);
 #pragma unroll
       for (int i = 0; i < NGI; ++i) {
         float v = 0.f;
         if (ok && n0 + gcs + i * GCPI < N && (NGI * GCPI == NBW || gcs + i * GCPI < NBW)) {
-          v = a.gout[off + (unsigned)(i * GCPI) * (unsigned)HW];
+          v = a.gout[off + (unsigned)(i * GCPI) * (unsigned)HWo];
           if (a.gscale) v *= a.gscale[srow + i * GCPI];
         }
         gr[i] = v;
       }
     }
     {
-      const int gy = y0 + hy - PAD, gx = x0 + hx - PAD, b = b0 + himg;
-      const bool ok = hlane && b < a.B && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      const int gy = y0 * IS + hy - PAD, gx = x0 * IS + hx - PAD, b = b0 + himg;
+      const bool ok = hlane && b < a.B && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi;
       const unsigned srow = (unsigned)(b * K + k0 + hcs);
-      const unsigned off = srow * (unsigned)HW + (unsigned)(gy * W + gx);
+      const unsigned off = srow * (unsigned)HWi + (unsigned)(gy * Wi + gx);
 #pragma unroll
       for (int i = 0; i < NHI; ++i) {
         float v = 0.f;
         if (ok && k0 + hcs + i * HCPI < K && (NHI * HCPI == KBW || hcs + i * HCPI < KBW)) {
-          v = a.in[off + (unsigned)(i * HCPI) * (unsigned)HW];
+          v = a.in[off + (unsigned)(i * HCPI) * (unsigned)HWi];
           if (a.iscale) v *= a.iscale[srow + i * HCPI];
         }
         hr[i] = v;
@@ -327,27 +352,33 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
 
 #pragma unroll
     for (int q = 0; q < PC / 2 / WS; ++q) {
-      const int ks = q * WS;  // this wave's pixel pair is ks + ws
+      // this wave's pixel pair: compile-time when WS == 1, else one of WS runtime alternatives
       float av;
       float bv[TAPS];
-      if constexpr (WS == 1) {
-        const int p0 = ks * 2;
-        const int hoff = (p0 / (G::TW * G::TH)) * G::IMS + ((p0 / G::TW) % G::TH) * G::TWp + (p0 % G::TW);
+      auto rd = [&](int p0) __attribute__((always_inline)) {
+        const int hoff = (p0 / (G::TW * G::TH)) * G::IMS + ((p0 / G::TW) % G::TH) * IS * G::TWp + (p0 % G::TW) * IS;
         av = Ga[p0];
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) bv[t] = Xa[hoff + (PAD ? (t / 3) * G::TWp + (t % 3) : 0)];
-      } else {
-        const int p0 = (ks + ws) * 2;
-        const int hoff = (p0 / (G::TW * G::TH)) * G::IMS + ((p0 / G::TW) % G::TH) * G::TWp + (p0 % G::TW);
-        av = Ga[p0];
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) bv[t] = Xa[hoff + (PAD ? (t / 3) * G::TWp + (t % 3) : 0)];
-      }
+      };
+      if constexpr (WS == 1) rd(q * 2);
+      else rd((q * WS + ws) * 2);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
     }
   }
 
+  if (a.gw != nullptr) {  // WS == 1 and one split: this block's tile IS the result
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int k = k0 + wk * 32 + (lane & 31);
+        if (n < N && k < K) a.gw[((size_t)n * K + k) * TAPS + t] = acc[t][r];
+      }
+    return;
+  }
   // slab[split*WS + ws][t][n][k]: D[i = n][j = k]
   float *sb = a.slab + ((size_t)blockIdx.y * WS + ws) * TAPS * a.Np32 * a.Kp32;
 #pragma unroll
@@ -360,22 +391,33 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
     }
 }
 
-// gw[n][k][t] = sum_s slab[s][t][n][k]
+// gw[n][k][t] = sum_s slab[s][t][n][k].  One block per (n, tap, 32 k's): 32 lanes along k x 8 groups of
+// splits, fixed-order combine through LDS (deterministic).
 template <int TAPS>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ slab, float *__restrict__ gw, int N, int K,
                                                       int Np32, int Kp32, int splits) {
-  const int k = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-  if (k >= K) return;
-  float s[TAPS];
-#pragma unroll
-  for (int t = 0; t < TAPS; ++t) s[t] = 0.f;
+  __shared__ float part[8][32];
+  const int kx = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int k = blockIdx.x * 32 + kx, t = blockIdx.y, n = blockIdx.z;
   const size_t sstride = (size_t)TAPS * Np32 * Kp32;
-  for (int sp = 0; sp < splits; ++sp)
+  const float *p = slab + ((size_t)t * Np32 + n) * Kp32 + k;   // k < Kp32 always (Kp32 is a multiple of 32)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int sp = grp;
+  for (; sp + 24 < splits; sp += 32) {
+    s0 += p[(size_t)sp * sstride];
+    s1 += p[(size_t)(sp + 8) * sstride];
+    s2 += p[(size_t)(sp + 16) * sstride];
+    s3 += p[(size_t)(sp + 24) * sstride];
+  }
+  for (; sp < splits; sp += 8) s0 += p[(size_t)sp * sstride];
+  part[grp][kx] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && k < K) {
+    float v = 0.f;
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) s[t] += slab[sp * sstride + ((size_t)t * Np32 + n) * Kp32 + k];
-  float *o = gw + ((size_t)n * K + k) * TAPS;
-#pragma unroll
-  for (int t = 0; t < TAPS; ++t) o[t] = s[t];
+    for (int g2 = 0; g2 < 8; ++g2) v += part[g2][kx];
+    gw[((size_t)n * K + k) * TAPS + t] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,36 +458,54 @@ inline int ceil_log2(int v) {
 }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// pixel-tile geometry for MB pixels per block: TW = min(32, pow2ceil(max(W,4))), TH = min(pow2ceil(max(H,4)), MB/TW)
-Geom make_geom(int MB, int B, int H, int W, int pad, bool odd_chs) {
+// pixel-tile geometry for MB compute-grid pixels per block over an Hc x Wc grid; taps span [lo, hi] in y and x
+Geom make_geom(int MB, int B, int Hc, int Wc, int IS, int lo_y, int hi_y, int lo_x, int hi_x, bool odd_chs,
+               int min_t = 4) {
   Geom g;
-  int lTW = ceil_log2(W < 4 ? 4 : W);
+  int lTW = ceil_log2(Wc < min_t ? min_t : Wc);
   if (lTW > 5) lTW = 5;
   const int lMB = ceil_log2(MB);
   if (lTW > lMB - 1) lTW = lMB - 1;
-  int lTH = ceil_log2(H < 4 ? 4 : H);
+  int lTH = ceil_log2(Hc < min_t ? min_t : Hc);
   if (lTH > lMB - lTW) lTH = lMB - lTW;
   g.lTW = lTW; g.lTH = lTH; g.lNI = lMB - lTW - lTH;
   const int TW = 1 << lTW, TH = 1 << lTH, NI = 1 << g.lNI;
-  g.TWp = TW + 2 * pad;
-  g.IMS = (TH + 2 * pad) * g.TWp;
+  g.TWp = (TW - 1) * IS + 1 + (hi_x - lo_x);
+  g.IMS = ((TH - 1) * IS + 1 + (hi_y - lo_y)) * g.TWp;
   g.HALO = NI * g.IMS;
   g.CHS = odd_chs ? (g.HALO | 1) : g.HALO;
   g.inv_TWp = 1.0f / (float)g.TWp;
   g.inv_IMS = 1.0f / (float)g.IMS;
   g.inv_HALO = 1.0f / (float)g.HALO;
-  g.tiles_x = (W + TW - 1) / TW;
-  g.tiles_y = (H + TH - 1) / TH;
+  g.tiles_x = (Wc + TW - 1) / TW;
+  g.tiles_y = (Hc + TH - 1) / TH;
   g.groups = (B + NI - 1) / NI;
+  g.lo_y = lo_y; g.lo_x = lo_x;
   return g;
 }
 
-template <int WC, int WP, int TC, int TP, int TAPS, int KC>
-int launch_conv(ConvArgs a, hipStream_t st) {
+// tap list of one launch: offsets (dy, dx) in input coordinates relative to pixel*IS, and the packed-weight tap
+struct Taps {
+  int n, ntx, dy[9], dx[9], w[9];   // ntx = taps per row of the (rows x ntx) tap grid
+};
+
+template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM = false>
+int launch_conv(ConvArgs a, const Taps &tp, hipStream_t st) {
   constexpr int NB = WC * TC * 32, MB = WP * TP * 32, NT = WC * WP * 64;
-  a.g = make_geom(MB, a.B, a.H, a.W, TAPS == 9 ? 1 : 0, false);
+  int lo_y = 0, hi_y = 0, lo_x = 0, hi_x = 0;
+  for (int t = 0; t < TAPS; ++t) {
+    lo_y = tp.dy[t] < lo_y ? tp.dy[t] : lo_y; hi_y = tp.dy[t] > hi_y ? tp.dy[t] : hi_y;
+    lo_x = tp.dx[t] < lo_x ? tp.dx[t] : lo_x; hi_x = tp.dx[t] > hi_x ? tp.dx[t] : hi_x;
+  }
+  a.g = make_geom(MB, a.B, a.Hc, a.Wc, IS, lo_y, hi_y, lo_x, hi_x, false, SM ? 2 : 4);
+  for (int t = 0; t < TAPS; ++t) a.toff[t] = (tp.dy[t] - lo_y) * a.g.TWp + (tp.dx[t] - lo_x);
+  // the tap lists built below are (rows x ntx) grids, so the packed-weight tap index is affine in (t / ntx, t % ntx)
+  a.ntx = tp.ntx;
+  a.wrow0 = tp.w[0] * a.Kp;
+  a.wrow_dx = tp.ntx > 1 ? (tp.w[1] - tp.w[0]) * a.Kp : 0;
+  a.wrow_dy = TAPS > tp.ntx ? (tp.w[tp.ntx] - tp.w[0]) * a.Kp : 0;
   const size_t lds = ((size_t)TAPS * KC * NB + (size_t)KC * a.g.CHS) * sizeof(float);
-  auto kern = k_conv<WC, WP, TC, TP, TAPS, KC>;
+  auto kern = k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -456,42 +516,48 @@ int launch_conv(ConvArgs a, hipStream_t st) {
   return HG_OK;
 }
 
-template <int TAPS>
-int dispatch_conv(const ConvArgs &a, hipStream_t st) {
-  const long long pix = (long long)a.B * a.H * a.W;
+template <int TAPS, int IS>
+int dispatch_conv(const ConvArgs &a, const Taps &tp, hipStream_t st) {
+  constexpr int KC = IS == 2 ? 4 : 8;
+  const long long pix = (long long)a.B * a.Hc * a.Wc;
   const int N = a.N;
-  // blocks each tile shape would launch; pick the largest tile that still gives >= ~2 blocks per CU
+  // blocks each tile shape would launch; pick the largest tile that still gives >= ~1.5 blocks per CU.
+  // Wide tiles need wide rows (the staging-register bound R16 in k_conv): 256-pixel tiles Wc > 8, 128-pixel Wc > 4.
   auto blocks = [&](int nb, int mb) { return ((N + nb - 1) / nb) * ((pix + mb - 1) / mb); };
-  if (N <= 32) return launch_conv<1, 4, 1, 2, TAPS, 8>(a, st);              // 32 ch x 256 px
-  if (N <= 64) {
-    if (blocks(64, 256) >= 384) return launch_conv<1, 4, 2, 2, TAPS, 8>(a, st);   // 64 ch x 256 px
-    return launch_conv<2, 2, 1, 1, TAPS, 16>(a, st);                        // 64 ch x 64 px
-  }
-  if (blocks(128, 128) >= 384) return launch_conv<2, 2, 2, 2, TAPS, 8>(a, st);    // 128 ch x 128 px
-  return launch_conv<2, 2, 1, 1, TAPS, 16>(a, st);                          // 64 ch x 64 px
+  const bool wide256 = a.Wc > 8 && a.Hc > 8, wide128 = a.Wc > 4 && a.Hc > 4;
+  if (N <= 32 && wide256) return launch_conv<1, 4, 1, 2, TAPS, KC, IS>(a, tp, st);                       // 32 ch x 256 px
+  if (N <= 64 && wide256 && blocks(64, 256) >= 384) return launch_conv<1, 4, 2, 2, TAPS, KC, IS>(a, tp, st);  // 64 ch x 256 px
+  if (N > 64 && wide128 && blocks(128, 128) >= 384) return launch_conv<2, 2, 2, 2, TAPS, KC, IS>(a, tp, st);  // 128 ch x 128 px
+  return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, IS == 1>(a, tp, st);                                   // 64 ch x 64 px
 }
 
 struct WgradPlan {
-  int lTW, tiles_x, tiles_y, groups;
+  int PC, lTW, tiles_x, tiles_y, groups;
   int WN, WK, WS;  // waves per block along n / k / pixel split
   int nchunks, splits, ktiles, ntiles, Kp32, Np32;
   size_t slab_bytes;
 };
 
-constexpr int WG_PC = 64;
+inline int out_size(int in, int stride) { return (in - 1) / stride + 1; }  // k = 3, pad 1 (or k = 1, pad 0, stride 1)
 
-WgradPlan make_wgrad_plan(int B, int K, int N, int H, int W, int ksize) {
+WgradPlan make_wgrad_plan(int B, int K, int N, int Hi, int Wi, int ksize, int stride) {
   WgradPlan p;
-  int lTW = ceil_log2(W < 4 ? 4 : W);
+  const int Ho = out_size(Hi, stride), Wo = out_size(Wi, stride);
+  p.PC = stride == 2 ? 32 : 64;
+  int lTW = ceil_log2(Wo < 2 ? 2 : Wo);
   if (lTW > 5) lTW = 5;
   p.lTW = lTW;
-  const int TW = 1 << lTW, TH = (WG_PC / TW) < TW ? (WG_PC / TW) : TW, NI = WG_PC / (TW * TH);
-  p.tiles_x = (W + TW - 1) / TW;
-  p.tiles_y = (H + TH - 1) / TH;
+  const int TW = 1 << lTW, TH = (p.PC / TW) < TW ? (p.PC / TW) : TW, NI = p.PC / (TW * TH);
+  p.tiles_x = (Wo + TW - 1) / TW;
+  p.tiles_y = (Ho + TH - 1) / TH;
   p.groups = (B + NI - 1) / NI;
   p.nchunks = p.tiles_x * p.tiles_y * p.groups;
-  p.WN = N > 32 ? 2 : 1;
-  p.WK = K > 32 ? 2 : 1;
+  if (stride == 2) {  // only two shapes are instantiated for stride 2
+    p.WN = p.WK = (N > 32 && K > 32) ? 2 : 1;
+  } else {
+    p.WN = N > 32 ? 2 : 1;
+    p.WK = K > 32 ? 2 : 1;
+  }
   p.WS = 4 / (p.WN * p.WK);
   p.ktiles = (K + p.WK * 32 - 1) / (p.WK * 32);
   p.ntiles = (N + p.WN * 32 - 1) / (p.WN * 32);
@@ -506,11 +572,12 @@ WgradPlan make_wgrad_plan(int B, int K, int N, int H, int W, int ksize) {
   return p;
 }
 
-template <int WN, int WK, int WS, int TAPS, int LTW>
+template <int WN, int WK, int WS, int TAPS, int LTW, int IS>
 int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
-  using G = CGeom<WG_PC, LTW, TAPS == 9 ? 1 : 0>;
-  const size_t lds = ((size_t)WN * 32 * (WG_PC + 1) + (size_t)WK * 32 * G::CHS) * sizeof(float);
-  auto kern = k_wgrad<WN, WK, WS, TAPS, WG_PC, LTW>;
+  constexpr int PC = IS == 2 ? 32 : 64;
+  using G = CGeom<PC, LTW, TAPS == 9 ? 1 : 0, IS>;
+  const size_t lds = ((size_t)WN * 32 * (PC + 1) + (size_t)WK * 32 * G::CHS) * sizeof(float);
+  auto kern = k_wgrad<WN, WK, WS, TAPS, PC, LTW, IS>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -520,35 +587,40 @@ int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
   return HG_OK;
 }
 
-template <int TAPS, int LTW>
+template <int TAPS, int LTW, int IS>
 int launch_wgrad_g(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
-  if (p.WN == 2 && p.WK == 2) return launch_wgrad_k<2, 2, 1, TAPS, LTW>(a, p, st);
-  if (p.WN == 2) return launch_wgrad_k<2, 1, 2, TAPS, LTW>(a, p, st);
-  if (p.WK == 2) return launch_wgrad_k<1, 2, 2, TAPS, LTW>(a, p, st);
-  return launch_wgrad_k<1, 1, 4, TAPS, LTW>(a, p, st);
+  if (p.WN == 2 && p.WK == 2) return launch_wgrad_k<2, 2, 1, TAPS, LTW, IS>(a, p, st);
+  if constexpr (IS == 1) {
+    if (p.WN == 2) return launch_wgrad_k<2, 1, 2, TAPS, LTW, IS>(a, p, st);
+    if (p.WK == 2) return launch_wgrad_k<1, 2, 2, TAPS, LTW, IS>(a, p, st);
+  }
+  return launch_wgrad_k<1, 1, 4, TAPS, LTW, IS>(a, p, st);
 }
 
-template <int TAPS>
+template <int TAPS, int IS>
 int launch_wgrad(WgradArgs a, const WgradPlan &p, float *gw, hipStream_t st) {
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
   a.nchunks = p.nchunks; a.splits = p.splits; a.ktiles = p.ktiles; a.Kp32 = p.Kp32; a.Np32 = p.Np32;
+  a.gw = (p.splits * p.WS == 1) ? gw : nullptr;
   int rc;
   switch (p.lTW) {
-    case 2: rc = launch_wgrad_g<TAPS, 2>(a, p, st); break;
-    case 3: rc = launch_wgrad_g<TAPS, 3>(a, p, st); break;
-    case 4: rc = launch_wgrad_g<TAPS, 4>(a, p, st); break;
-    default: rc = launch_wgrad_g<TAPS, 5>(a, p, st); break;
+    case 1: rc = launch_wgrad_g<TAPS, 1, IS>(a, p, st); break;
+    case 2: rc = launch_wgrad_g<TAPS, 2, IS>(a, p, st); break;
+    case 3: rc = launch_wgrad_g<TAPS, 3, IS>(a, p, st); break;
+    case 4: rc = launch_wgrad_g<TAPS, 4, IS>(a, p, st); break;
+    default: rc = launch_wgrad_g<TAPS, 5, IS>(a, p, st); break;
   }
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_wgrad_reduce<TAPS>, dim3((unsigned)((a.K + 255) / 256), (unsigned)a.N), dim3(256), 0, st, a.slab, gw,
-                     a.N, a.K, p.Np32, p.Kp32, p.splits * p.WS);
+  if (rc || a.gw) return rc;
+  hipLaunchKernelGGL(k_wgrad_reduce<TAPS>, dim3((unsigned)((a.K + 31) / 32), (unsigned)TAPS, (unsigned)a.N), dim3(256), 0, st,
+                     a.slab, gw, a.N, a.K, p.Np32, p.Kp32, p.splits * p.WS);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
 
-inline bool conv_args_ok(int B, int K, int N, int H, int W, int ksize) {
+inline bool conv_args_ok(int B, int K, int N, int H, int W, int ksize, int stride) {
   if (B <= 0 || K <= 0 || N <= 0 || H <= 0 || W <= 0) return false;
   if (ksize != 1 && ksize != 3) return false;
+  if (stride != 1 && !(stride == 2 && ksize == 3)) return false;
   return true;
 }
 inline bool fits_i32(int B, int K, int N, int H, int W) {
@@ -583,34 +655,94 @@ int hg_conv_pack_weights(const float *w, float *wt, int32_t Co, int32_t Ci, int3
   return HG_OK;
 }
 
-int hg_conv2d_same(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
-                   const float *bias, int32_t B, int32_t K, int32_t N, int32_t H, int32_t W, int32_t ksize,
-                   void *stream) {
-  if (!in || !wt || !out || !conv_args_ok(B, K, N, H, W, ksize)) return HG_EINVAL;
-  if (!fits_i32(B, K, N, H, W)) return HG_EUNSUPPORTED;
+int hg_conv2d_fwd(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
+                  const float *bias, int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
+                  int32_t stride, void *stream) {
+  if (!in || !wt || !out || !conv_args_ok(B, K, N, Hi, Wi, ksize, stride)) return HG_EINVAL;
+  if (!fits_i32(B, K, N, Hi, Wi)) return HG_EUNSUPPORTED;
   ConvArgs a;
   a.in = in; a.wt = wt; a.out = out; a.iscale = iscale; a.oscale = oscale; a.bias = bias;
-  a.B = B; a.K = K; a.N = N; a.H = H; a.W = W;
+  a.B = B; a.K = K; a.N = N; a.Hi = Hi; a.Wi = Wi;
+  a.Ho = a.Hc = out_size(Hi, stride); a.Wo = a.Wc = out_size(Wi, stride);
+  a.os = 1; a.oy = a.ox = 0;
   a.Kp = round_up(K, 16); a.Np = round_up(N, 128);
-  return ksize == 3 ? dispatch_conv<9>(a, (hipStream_t)stream) : dispatch_conv<1>(a, (hipStream_t)stream);
+  Taps tp;
+  hipStream_t st = (hipStream_t)stream;
+  if (ksize == 1) {
+    tp.n = 1; tp.ntx = 1; tp.dy[0] = tp.dx[0] = 0; tp.w[0] = 0;
+    return dispatch_conv<1, 1>(a, tp, st);
+  }
+  tp.n = 9; tp.ntx = 3;
+  for (int t = 0; t < 9; ++t) { tp.dy[t] = t / 3 - 1; tp.dx[t] = t % 3 - 1; tp.w[t] = t; }
+  return stride == 1 ? dispatch_conv<9, 1>(a, tp, st) : dispatch_conv<9, 2>(a, tp, st);
 }
 
-size_t hg_conv2d_wgrad_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t H, int32_t W, int32_t ksize) {
-  if (!conv_args_ok(B, K, N, H, W, ksize)) return 0;
-  return make_wgrad_plan(B, K, N, H, W, ksize).slab_bytes;
+int hg_conv2d_dgrad(const float *gout, const float *wt, float *gin, const float *iscale, const float *oscale,
+                    int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride,
+                    void *stream) {
+  if (!gout || !wt || !gin || !conv_args_ok(B, K, N, Hi, Wi, ksize, stride)) return HG_EINVAL;
+  if (!fits_i32(B, K, N, Hi, Wi)) return HG_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  ConvArgs a;
+  a.in = gout; a.wt = wt; a.out = gin; a.iscale = iscale; a.oscale = oscale; a.bias = nullptr;
+  a.B = B; a.K = K; a.N = N;
+  a.Hi = out_size(Hi, stride); a.Wi = out_size(Wi, stride);  // the kernel's input is grad_out
+  a.Ho = Hi; a.Wo = Wi;
+  a.Kp = round_up(K, 16); a.Np = round_up(N, 128);
+  Taps tp;
+  if (stride == 1) {
+    a.Hc = Hi; a.Wc = Wi; a.os = 1; a.oy = a.ox = 0;
+    if (ksize == 1) {
+      tp.n = 1; tp.ntx = 1; tp.dy[0] = tp.dx[0] = 0; tp.w[0] = 0;
+      return dispatch_conv<1, 1>(a, tp, st);
+    }
+    tp.n = 9; tp.ntx = 3;
+    for (int t = 0; t < 9; ++t) { tp.dy[t] = t / 3 - 1; tp.dx[t] = t % 3 - 1; tp.w[t] = t; }
+    return dispatch_conv<9, 1>(a, tp, st);
+  }
+  // stride 2: gin[2y+pY, 2x+pX] = sum over the taps (dy,dx) with dy == pY+1, dx == pX+1 (mod 2) of
+  //           gout[y + (pY+1-dy)/2, x + (pX+1-dx)/2] * W[.,.,dy,dx];  the dgrad packing stores W[dy,dx] at tap 8-(3dy+dx)
+  a.os = 2;
+  for (int pY = 0; pY < 2; ++pY)
+    for (int pX = 0; pX < 2; ++pX) {
+      a.Hc = (Hi - pY + 1) / 2; a.Wc = (Wi - pX + 1) / 2;
+      if (a.Hc <= 0 || a.Wc <= 0) continue;
+      a.oy = pY; a.ox = pX;
+      tp.n = 0; tp.ntx = pX ? 2 : 1;
+      for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx)
+          if (((pY + 1 - dy) & 1) == 0 && ((pX + 1 - dx) & 1) == 0) {
+            tp.dy[tp.n] = (pY + 1 - dy) / 2; tp.dx[tp.n] = (pX + 1 - dx) / 2; tp.w[tp.n] = 8 - (3 * dy + dx);
+            ++tp.n;
+          }
+      int rc;
+      if (tp.n == 1) rc = dispatch_conv<1, 1>(a, tp, st);
+      else if (tp.n == 2) rc = dispatch_conv<2, 1>(a, tp, st);
+      else rc = dispatch_conv<4, 1>(a, tp, st);
+      if (rc) return rc;
+    }
+  return HG_OK;
+}
+
+size_t hg_conv2d_wgrad_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
+                                       int32_t stride) {
+  if (!conv_args_ok(B, K, N, Hi, Wi, ksize, stride)) return 0;
+  return make_wgrad_plan(B, K, N, Hi, Wi, ksize, stride).slab_bytes;
 }
 
 int hg_conv2d_wgrad(const float *in, const float *gout, float *gw, const float *iscale, const float *gscale, int32_t B,
-                    int32_t K, int32_t N, int32_t H, int32_t W, int32_t ksize, void *workspace, size_t workspace_bytes,
-                    void *stream) {
-  if (!in || !gout || !gw || !workspace || !conv_args_ok(B, K, N, H, W, ksize)) return HG_EINVAL;
-  if (!fits_i32(B, K, N, H, W)) return HG_EUNSUPPORTED;
-  const WgradPlan p = make_wgrad_plan(B, K, N, H, W, ksize);
+                    int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride, void *workspace,
+                    size_t workspace_bytes, void *stream) {
+  if (!in || !gout || !gw || !workspace || !conv_args_ok(B, K, N, Hi, Wi, ksize, stride)) return HG_EINVAL;
+  if (!fits_i32(B, K, N, Hi, Wi)) return HG_EUNSUPPORTED;
+  const WgradPlan p = make_wgrad_plan(B, K, N, Hi, Wi, ksize, stride);
   if (workspace_bytes < p.slab_bytes) return HG_EWORKSPACE;
   WgradArgs a;
   a.in = in; a.gout = gout; a.slab = (float *)workspace; a.iscale = iscale; a.gscale = gscale;
-  a.B = B; a.K = K; a.N = N; a.H = H; a.W = W;
-  return ksize == 3 ? launch_wgrad<9>(a, p, gw, (hipStream_t)stream) : launch_wgrad<1>(a, p, gw, (hipStream_t)stream);
+  a.B = B; a.K = K; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ho = out_size(Hi, stride); a.Wo = out_size(Wi, stride);
+  hipStream_t st = (hipStream_t)stream;
+  if (ksize == 1) return launch_wgrad<1, 1>(a, p, gw, st);
+  return stride == 1 ? launch_wgrad<9, 1>(a, p, gw, st) : launch_wgrad<9, 2>(a, p, gw, st);
 }
 
 }  // extern "C"

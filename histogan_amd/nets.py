@@ -9,8 +9,9 @@ execution plan:
   (no B x O x I x k x k per-sample weights, no grouped conv, no MIOpen).
 * GeneratorBlock (reference :443-502) fuses the bilinear x2 upsample into conv1's prologue and the
   noise add + LeakyReLU(0.2) (+ demodulation) into each conv's epilogue.
-* Discriminator / vectorizers are plain PyTorch-ROCm modules (MIOpen / rocBLAS): the discriminator must
-  stay twice differentiable for the gradient penalty (reference :156-163).
+* Discriminator (reference :505-631): every convolution (3x3, 1x1, 3x3 stride 2) runs on the same MFMA
+  implicit-GEMM kernels through autograd Functions that are differentiable to any order (the gradient
+  penalty, reference :156-163, needs the second); LeakyReLU / residual add / Linear stay torch ops.
 """
 from math import log2
 
@@ -19,7 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from .conv import conv2d_same
+from .conv import conv2d, conv2d_same
 
 EPS = 1e-8  # histoGAN/histoGAN.py:53
 
@@ -200,13 +201,25 @@ class StyleVectorizer(nn.Module):
         return self.net(x)
 
 
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters, init and state_dict keys) whose forward runs on the MFMA implicit-GEMM
+    kernels: 1x1 / 3x3, stride 1 or 2, padding k//2 -- every convolution of the discriminator (:510-518)."""
+
+    def forward(self, x):
+        k = self.kernel_size[0]
+        if (self.kernel_size[0] != self.kernel_size[1] or self.padding != (k // 2, k // 2) or self.dilation != (1, 1)
+                or self.groups != 1 or self.stride[0] != self.stride[1] or self.padding_mode != 'zeros'):
+            raise NotImplementedError('Conv2d: only square 1x1/3x3, padding k//2, stride 1/2, dilation 1, groups 1')
+        return conv2d(x, self.weight, self.bias, self.stride[0])
+
+
 class DiscriminatorBlock(nn.Module):
     def __init__(self, input_channels, filters, downsample=True):
         super().__init__()
-        self.conv_res = nn.Conv2d(input_channels, filters, 1)
-        self.net = nn.Sequential(nn.Conv2d(input_channels, filters, 3, padding=1), leaky_relu(),
-                                 nn.Conv2d(filters, filters, 3, padding=1), leaky_relu())
-        self.downsample = nn.Conv2d(filters, filters, 3, padding=1, stride=2) if downsample else None
+        self.conv_res = Conv2d(input_channels, filters, 1)
+        self.net = nn.Sequential(Conv2d(input_channels, filters, 3, padding=1), leaky_relu(),
+                                 Conv2d(filters, filters, 3, padding=1), leaky_relu())
+        self.downsample = Conv2d(filters, filters, 3, padding=1, stride=2) if downsample else None
 
     def forward(self, x):
         res = self.conv_res(x)

@@ -11,6 +11,7 @@ import ctypes
 import torch
 
 from ._lib import check, lib
+from .conv import weights_changed
 
 
 def _st(t):
@@ -80,6 +81,7 @@ class DiffGrad:
                                        self.exp_avg_sq.data_ptr(), self.previous_grad.data_ptr(), f.numel,
                                        float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                        self.step_count, _st(f.data)), 'hg_diffgrad_step')
+        weights_changed()
 
 
 def ema_update(ma_flat, cur_flat, beta):

@@ -28,6 +28,7 @@ from torch import nn
 from torch.autograd import grad as torch_grad
 
 from . import ddp
+from .conv import enable_pack_cache, input_grads_only, weights_changed
 from .hist import hellinger_loss
 from .nets import Discriminator, Generator, HistVectorizer, StyleVectorizer
 from .optim import DiffGrad, FlatParams, ema_update
@@ -73,8 +74,9 @@ def set_requires_grad(model, bool):
 def gradient_penalty(images, output, weight=10):
     """10 * mean((||grad_x D(x)||_2 - 1)^2) on real images, double-differentiable (reference :156-163)."""
     batch_size = images.shape[0]
-    gradients = torch_grad(outputs=output, inputs=images, grad_outputs=torch.ones_like(output),
-                           create_graph=True, retain_graph=True, only_inputs=True)[0]
+    with input_grads_only():    # d output / d images only: no conv node computes an (unused) weight gradient
+        gradients = torch_grad(outputs=output, inputs=images, grad_outputs=torch.ones_like(output),
+                               create_graph=True, retain_graph=True, only_inputs=True)[0]
     gradients = gradients.reshape(batch_size, -1)
     return weight * ((gradients.norm(2, dim=1) - 1) ** 2).mean()
 
@@ -167,10 +169,12 @@ class HistoGAN(nn.Module):
             ddp.broadcast_flat(f)
         self._reduce_g = ddp.GradAllReduce(self._flat_g)
         self._reduce_d = ddp.GradAllReduce(self._flat_d)
+        # packed conv weights are reused between the forward passes of one step (invalidated by the optimizers)
+        enable_pack_cache(list(self.G.parameters()) + list(self.D.parameters()) + list(self.GE.parameters()))
 
     def _init_weights(self):
         for m in self.modules():
-            if type(m) in {nn.Conv2d, nn.Linear}:
+            if isinstance(m, (nn.Conv2d, nn.Linear)):
                 nn.init.kaiming_normal_(m.weight, a=0, mode='fan_in', nonlinearity='leaky_relu')
         for block in self.G.blocks:
             nn.init.zeros_(block.to_noise1.weight)
@@ -371,6 +375,9 @@ class Trainer():
 
         # ---- generator phase (reference :934-989)
         GAN.G_opt.zero_grad()
+        # The reference lets the G-phase backward deposit gradients in D as well and throws them away at the
+        # next D_opt.zero_grad() (:889); not computing them is the same result without D's weight-gradient pass.
+        set_requires_grad(Disc, False)
         d_updated = False
         for i in range(acc):
             style = get_latents_fn(batch_size, num_layers - 2, latent_dim)
@@ -402,6 +409,7 @@ class Trainer():
             gen_loss.backward()
             total_gen_loss += loss.detach() / acc
             total_hist_loss += histogram_loss.detach() / acc
+        set_requires_grad(Disc, True)
         GAN._reduce_g()
         GAN.G_opt.step()
 
@@ -544,3 +552,4 @@ class Trainer():
             print(f'continuing from previous epoch - {name}')
         self.steps = name * self.save_every
         self.GAN.load_state_dict(torch.load(self.model_name(name), map_location=self.device))
+        weights_changed()

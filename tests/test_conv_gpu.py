@@ -18,6 +18,62 @@ CASES = [
 ]
 
 
+# stride-2 cases (3x3): the discriminator's down-sampling convolution (histoGAN/histoGAN.py:517-518)
+CASES_S2 = [(2, 16, 16, 32, 32), (3, 5, 7, 9, 13), (2, 64, 64, 16, 16), (4, 70, 130, 8, 8), (2, 32, 32, 64, 64),
+            (1, 3, 4, 5, 4), (8, 128, 128, 4, 4), (2, 16, 16, 128, 128), (5, 33, 65, 2, 2), (1, 2, 2, 1, 1)]
+
+
+@pytest.mark.parametrize('B,K,N,H,W', CASES_S2)
+def test_conv2d_stride2_matches_fp64(B, K, N, H, W, gpu_device):
+    from histogan_amd.conv import conv2d
+    g = torch.Generator(device='cpu').manual_seed(B * 1000 + K * 10 + N + H)
+    x = torch.randn(B, K, H, W, generator=g).to(gpu_device).requires_grad_(True)
+    w = (torch.randn(N, K, 3, 3, generator=g) / (K * 9) ** 0.5).to(gpu_device).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(gpu_device).requires_grad_(True)
+    out = conv2d(x, w, b, stride=2)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    ref = F.conv2d(xd, wd, bd, stride=2, padding=1)
+    assert out.shape == ref.shape
+    go = torch.randn(ref.shape, generator=g).to(gpu_device)
+    gx, gw, gb = torch.autograd.grad(out, (x, w, b), go)
+    rx, rw, rb = torch.autograd.grad(ref, (xd, wd, bd), go.double())
+    assert relmax(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 2e-6
+    assert relmax(gx.cpu().numpy(), rx.cpu().numpy()) <= 2e-6
+    assert relmax(gw.cpu().numpy(), rw.cpu().numpy()) <= 5e-6
+    assert relmax(gb.cpu().numpy(), rb.cpu().numpy()) <= 5e-6
+
+
+@pytest.mark.parametrize('stride,k', [(1, 3), (2, 3), (1, 1)])
+def test_conv2d_double_backward(stride, k, gpu_device):
+    """Gradient-penalty pattern (histoGAN/histoGAN.py:156-163): d/dw and d/dx of || d out / d x ||^2 through a
+    conv -> lrelu -> conv stack, against torch's fp64 double backward."""
+    from histogan_amd.conv import conv2d, input_grads_only
+    torch.manual_seed(11)
+    B, K, N, H = 3, 6, 10, 12
+    x = torch.randn(B, K, H, H, device=gpu_device, requires_grad=True)
+    w1 = (torch.randn(N, K, k, k, device=gpu_device) / (K * k * k) ** 0.5).requires_grad_(True)
+    b1 = torch.randn(N, device=gpu_device, requires_grad=True)
+    w2 = (torch.randn(4, N, 3, 3, device=gpu_device) / (N * 9) ** 0.5).requires_grad_(True)
+
+    def penalty(conv, x, w1, b1, w2, ctx):
+        h = F.leaky_relu(conv(x, w1, b1, stride), 0.2)
+        out = conv(h, w2, None, 1).pow(2).sum(dim=(1, 2, 3))
+        with ctx():
+            gr, = torch.autograd.grad(out, x, torch.ones_like(out), create_graph=True)
+        return ((gr.reshape(B, -1).norm(2, dim=1) - 1) ** 2).mean()
+
+    import contextlib
+    ours = penalty(conv2d, x, w1, b1, w2, input_grads_only)
+    g_ours = torch.autograd.grad(ours, (x, w1, b1, w2))
+    xd, w1d, b1d, w2d = (t.detach().double().requires_grad_(True) for t in (x, w1, b1, w2))
+    ref = penalty(lambda a, w, b, s: F.conv2d(a, w, b, stride=s, padding=w.shape[2] // 2), xd, w1d, b1d, w2d,
+                  contextlib.nullcontext)
+    g_ref = torch.autograd.grad(ref, (xd, w1d, b1d, w2d))
+    assert abs(float(ours) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    for a, b in zip(g_ours, g_ref):
+        assert relmax(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
+
+
 @pytest.mark.parametrize('B,K,N,H,W,k', CASES)
 def test_conv2d_same_matches_fp64(B, K, N, H, W, k, gpu_device):
     from histogan_amd.conv import conv2d_same
@@ -51,12 +107,18 @@ def test_conv_fused_scales(gpu_device):
     s = torch.rand(B, K, device=gpu_device) + 0.5
     d = torch.rand(B, N, device=gpu_device) + 0.5
     bias = torch.randn(N, device=gpu_device)
-    out = C.conv_packed(x, C.pack_weights(w, C.PACK_FWD), N, 3, iscale=s, oscale=d, bias=bias)
+    out = C.conv_fwd_packed(x, C.pack_weights(w, C.PACK_FWD), N, 3, iscale=s, oscale=d, bias=bias)
     ref = F.conv2d((x * s[:, :, None, None]).double(), w.double(), padding=1) * d[:, :, None, None].double() \
         + bias[None, :, None, None].double()
     assert relmax(out.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
     go = torch.randn(B, N, H, W, device=gpu_device)
     gw = C.conv_wgrad(x, go, 3, iscale=s, gscale=d)
+    # data gradient with the scales swapped: gx = s * dgrad(d * go)
+    gx = C.conv_dgrad_packed(go, C.pack_weights(w, C.PACK_DGRAD), K, H, W, 3, iscale=d, oscale=s)
+    xr = x.double().requires_grad_(True)
+    rx, = torch.autograd.grad(F.conv2d(xr * s[:, :, None, None].double(), w.double(), padding=1), xr,
+                              (go * d[:, :, None, None]).double())
+    assert relmax(gx.cpu().numpy(), rx.cpu().numpy()) <= 2e-6
     xd = (x * s[:, :, None, None]).double()
     wd = w.double().requires_grad_(True)
     rw, = torch.autograd.grad(F.conv2d(xd, wd, padding=1), wd, (go * d[:, :, None, None]).double())
@@ -80,3 +142,6 @@ def test_conv_rejects_cpu_and_bad_kernel(gpu_device):
         conv2d_same(torch.randn(1, 2, 4, 4), torch.randn(3, 2, 3, 3))
     with pytest.raises(ValueError):
         conv2d_same(torch.randn(1, 2, 8, 8, device=gpu_device), torch.randn(3, 2, 5, 5, device=gpu_device))
+    from histogan_amd.conv import conv2d
+    with pytest.raises(ValueError):
+        conv2d(torch.randn(1, 2, 8, 8, device=gpu_device), torch.randn(3, 2, 1, 1, device=gpu_device), None, 2)

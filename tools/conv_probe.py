@@ -46,8 +46,8 @@ for K, N, S, k in LAYERS:
     go = torch.randn(B, N, S, S, device=dev)
     wf, wd = C.pack_weights(w, C.PACK_FWD), C.pack_weights(w, C.PACK_DGRAD)
     flops = 2.0 * B * S * S * K * N * k * k
-    tf = timeit(lambda: C.conv_packed(x, wf, N, k), args.iters)
-    td = timeit(lambda: C.conv_packed(go, wd, K, k), args.iters)
+    tf = timeit(lambda: C.conv_fwd_packed(x, wf, N, k), args.iters)
+    td = timeit(lambda: C.conv_dgrad_packed(go, wd, K, S, S, k), args.iters)
     tw = timeit(lambda: C.conv_wgrad(x, go, k), args.iters)
     tp = timeit(lambda: C.pack_weights(w, C.PACK_FWD), args.iters)
     line = (f'{K:5d} {N:5d} {S:4d} {k} | {tf*1e3:8.3f} {flops/tf/1e12:6.1f} | {td*1e3:8.3f} {flops/td/1e12:6.1f} | '
@@ -62,3 +62,29 @@ for K, N, S, k in LAYERS:
 print('generator 3x3 layers: fwd %.2f ms (%.1f TF)  dgrad %.2f ms (%.1f TF)  wgrad %.2f ms (%.1f TF)' % (
     tot['fwd'] * 1e3, tot['flops'] / tot['fwd'] / 1e12, tot['dgrad'] * 1e3, tot['flops'] / tot['dgrad'] / 1e12,
     tot['wgrad'] * 1e3, tot['flops'] / tot['wgrad'] / 1e12))
+
+# ---- discriminator shapes (256^2, cap 16): (K, N, S_in, ksize, stride)
+print('\ndiscriminator layers')
+DL = []
+f = [3, 16, 32, 64, 128, 256, 512, 1024, 2048]
+for i in range(8):
+    S = 256 >> i
+    DL += [(f[i], f[i + 1], S, 1, 1), (f[i], f[i + 1], S, 3, 1), (f[i + 1], f[i + 1], S, 3, 1)]
+    if i < 7:
+        DL.append((f[i + 1], f[i + 1], S, 3, 2))
+tt = dict(f=0.0, d=0.0, w=0.0, fl=0.0)
+for K, N, S, k, st in DL:
+    x = torch.randn(B, K, S, S, device=dev)
+    w = torch.randn(N, K, k, k, device=dev) / (K * k * k) ** 0.5
+    So = (S - 1) // st + 1
+    go = torch.randn(B, N, So, So, device=dev)
+    wf, wd = C.pack_weights(w, C.PACK_FWD), C.pack_weights(w, C.PACK_DGRAD)
+    flops = 2.0 * B * So * So * K * N * k * k
+    tf = timeit(lambda: C.conv_fwd_packed(x, wf, N, k, st), args.iters)
+    td = timeit(lambda: C.conv_dgrad_packed(go, wd, K, S, S, k, st), args.iters)
+    tw = timeit(lambda: C.conv_wgrad(x, go, k, st), args.iters)
+    print(f'{K:5d} {N:5d} {S:4d} k{k} s{st} | fwd {tf*1e3:7.3f} ms {flops/tf/1e12:6.1f} TF | dgrad {td*1e3:7.3f} {flops/td/1e12:6.1f} | '
+          f'wgrad {tw*1e3:7.3f} {flops/tw/1e12:6.1f}', flush=True)
+    tt['f'] += tf; tt['d'] += td; tt['w'] += tw; tt['fl'] += flops
+print('discriminator: fwd %.2f ms (%.1f TF)  dgrad %.2f ms (%.1f TF)  wgrad %.2f ms (%.1f TF)' % (
+    tt['f'] * 1e3, tt['fl'] / tt['f'] / 1e12, tt['d'] * 1e3, tt['fl'] / tt['d'] / 1e12, tt['w'] * 1e3, tt['fl'] / tt['w'] / 1e12))
