@@ -13,8 +13,11 @@ one process per GPU, RCCL all-reduce of the flat gradient buffers (weak scaling)
 Workload `hist` (BASELINE.json configs[1]): RGB-uv histogram forward + Hellinger loss + backward on a
 resident batch 32x3x256x256, h=64, inverse-quadratic sigma=0.02, insz=256 (N = 65 536 pixels/image).
 
-Both report `roofline` for the hand-written dominant histogram kernel (k_hist_bwd, timed with HIP events
-around the C-ABI calls at the configs[1] shape) and `cpu_baseline` (the oracle on host cores).
+`roofline` is the dominant hand-written kernel of the workload, timed live with HIP events around its C-ABI
+call: `train` -> k_conv (the fp32-MFMA implicit-GEMM convolution; >50 % of the step), at the generator layer
+256->128 channels, 64x64, batch 32 (the 128ch x 128px tile instantiation), with the weight-gradient kernel,
+the per-pass aggregates over all generator 3x3 layers and the histogram kernels as sub-objects;
+`hist` -> k_hist_bwd.  `cpu_baseline` = the oracle (CPU restatement of the reference) on the host cores.
 """
 import argparse
 import json
@@ -88,6 +91,102 @@ def hist_workload(args, dev, rank, world):
                                     bytes_bwd=bytes_bwd), info, B
 
 
+# generator 3x3 convolutions at 256^2 / capacity 16: (K, N, S)   
+G_LAYERS = [(64, 2048, 4), (2048, 2048, 4), (2048, 1024, 8), (1024, 1024, 8), (1024, 512, 16), (512, 512, 16),
+            (512, 256, 32), (256, 256, 32), (256, 128, 64), (128, 128, 64), (128, 64, 128), (64, 64, 128),
+            (64, 32, 256), (32, 32, 256)]
+
+
+def conv_kernel_times(dev, B, iters=6):
+    """HIP events (torch's current stream == the stream the C ABI launches on) around hg_conv2d_fwd /
+    hg_conv2d_dgrad / hg_conv2d_wgrad with preallocated buffers, for every generator 3x3 layer.
+    Returns {layer: (flops, t_fwd, t_dgrad, t_wgrad)} in seconds per launch."""
+    import ctypes
+    from histogan_amd import conv as C
+    from histogan_amd._lib import lib, check
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    out = {}
+    for K, N, S in G_LAYERS:
+        x = torch.randn(B, K, S, S, device=dev)
+        w = torch.randn(N, K, 3, 3, device=dev) / (K * 9) ** 0.5
+        go = torch.randn(B, N, S, S, device=dev)
+        y, gx, gw = torch.empty_like(go), torch.empty_like(x), torch.empty_like(w)
+        wf, wd = C.pack_weights(w, C.PACK_FWD), C.pack_weights(w, C.PACK_DGRAD)
+        nf = lib.hg_conv2d_workspace_bytes(B, K, N, S, S, 3, 1, 0)
+        nd = lib.hg_conv2d_workspace_bytes(B, N, K, S, S, 3, 1, 1)
+        nw = lib.hg_conv2d_wgrad_workspace_bytes(B, K, N, S, S, 3, 1)
+        ws = torch.empty(max(nf, nd, nw, 4), dtype=torch.uint8, device=dev)
+        calls = (
+            lambda: check(lib.hg_conv2d_fwd(x.data_ptr(), wf.data_ptr(), y.data_ptr(), None, None, None, B, K, N, S, S,
+                                            3, 1, ws.data_ptr(), ws.numel(), st), 'fwd'),
+            lambda: check(lib.hg_conv2d_dgrad(go.data_ptr(), wd.data_ptr(), gx.data_ptr(), None, None, B, N, K, S, S,
+                                              3, 1, ws.data_ptr(), ws.numel(), st), 'dgrad'),
+            lambda: check(lib.hg_conv2d_wgrad(x.data_ptr(), go.data_ptr(), gw.data_ptr(), None, None, B, K, N, S, S,
+                                              3, 1, ws.data_ptr(), ws.numel(), st), 'wgrad'))
+        ts = []
+        for fn in calls:
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / iters * 1e-3)
+        out[(K, N, S)] = (2.0 * B * S * S * K * N * 9, *ts)
+    return out
+
+
+def cpu_baseline_train(args):
+    """The oracle (CPU restatement of the reference networks + histogram block) doing the compute of one train
+    step -- D phase: G fwd (no grad), D on fake and real, backward; G phase: G fwd, D fwd, RGB-uv histogram +
+    Hellinger loss, backward; DiffGrad over all parameters -- on a bounded sample of the batch."""
+    import torch.nn.functional as F
+    from histogan_amd.nets import Discriminator, Generator, HistVectorizer, StyleVectorizer
+    from oracle import histogan_nets as N
+    from oracle import rgbuv_hist as O
+    S, cap, h, n = args.size, args.capacity, args.bins, args.cpu_images
+    L = int(__import__('math').log2(S)) - 1
+    torch.manual_seed(0)
+    sd = {k: {kk: v.detach().requires_grad_(True) for kk, v in m.state_dict(keep_vars=True).items()}
+          for k, m in dict(G=Generator(S, 512, cap), D=Discriminator(S, cap), S=StyleVectorizer(512, 8),
+                           H=HistVectorizer(h, 512, 8)).items()}
+    img = torch.rand(n, 3, S, S)
+    tgt = O.rgbuv_hist(torch.rand(n, 3, S, S), h=h, insz=150)
+
+    def gen(grad):
+        with torch.set_grad_enabled(grad):
+            w = N.vectorizer(sd['S'], torch.randn(n, 512), 'net')
+            hw = N.vectorizer(sd['H'], tgt, 'fcs')
+            return N.generator(sd['G'], w[:, None].expand(-1, L - 2, -1), hw[:, None].expand(-1, 2, -1),
+                               torch.rand(n, S, S, 1), L)
+
+    def one_step():
+        fake = gen(False)
+        real = img.clone().requires_grad_(True)
+        d = (F.relu(1 + N.discriminator(sd['D'], real, L + 1)) + F.relu(1 - N.discriminator(sd['D'], fake, L + 1))).mean()
+        torch.autograd.grad(d, list(sd['D'].values()), allow_unused=True)
+        fake = gen(True)
+        loss = N.discriminator(sd['D'], fake, L + 1).mean() + O.hellinger_loss(tgt, O.rgbuv_hist(F.relu(fake), h=h, insz=150), 2.0)
+        torch.autograd.grad(loss, [v for k in 'GSH' for v in sd[k].values()], allow_unused=True)
+
+    t0 = time.perf_counter()
+    one_step()
+    dt = time.perf_counter() - t0
+    # optimizer: DiffGrad over every parameter once per step (amortised over the full batch)
+    flat = torch.cat([v.detach().reshape(-1) for k in 'GDSH' for v in sd[k].values()])
+    state = dict(step=0, exp_avg=torch.zeros_like(flat), exp_avg_sq=torch.zeros_like(flat),
+                 previous_grad=torch.zeros_like(flat))
+    t0 = time.perf_counter()
+    N.diffgrad_step(flat, torch.randn_like(flat), state, 2e-4)
+    dto = time.perf_counter() - t0
+    per_img = dt / n + dto / args.batch
+    return dict(value=1.0 / per_img, unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'{n} of the {args.batch} images: one D phase + one G phase (no GP / PL step) {dt:.1f} s, '
+                       f'DiffGrad over {flat.numel()/1e6:.0f} M parameters {dto:.2f} s amortised over the batch; '
+                       f'torch CPU {torch.get_num_threads()} threads')
+
+
 def train_workload(args, dev, rank, world):
     from histoGAN import Trainer
     tr = Trainer('bench', '/tmp/hg_bench_results', '/tmp/hg_bench_models', args.size, args.capacity,
@@ -136,7 +235,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=256)
     ap.add_argument('--bins', type=int, default=64)
-    ap.add_argument('--cpu-images', type=int, default=4)
+    ap.add_argument('--cpu-images', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -177,25 +276,42 @@ def main():
         dt = float(t.item())
 
     t_fwd, t_bwd = time_kernels(min(max(args.steps, 5), 20))
+    hist_roof = {'kernel': 'k_hist_bwd', 'bound': 'mfma', 'achieved': work['flops_bwd'] / t_bwd / 1e12,
+                 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': work['flops_bwd'] / t_bwd / 1e12 / FP32_PEAK_TFLOPS,
+                 'traffic': None, 'launch_ms': t_bwd * 1e3,
+                 'fwd': {'kernel': 'k_hist_fwd', 'achieved': work['flops_fwd'] / t_fwd / 1e12,
+                         'frac': work['flops_fwd'] / t_fwd / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': t_fwd * 1e3}}
+    if args.workload == 'train':
+        ct = conv_kernel_times(dev, args.batch)
+        fl, tf, td, tw = ct[(256, 128, 64)]
+        tot = [sum(v[i] for v in ct.values()) for i in range(4)]
+        roof = {'kernel': 'k_conv<128ch x 128px tile, 3x3, stride 1> (hg_conv2d_fwd) at 256->128 ch, 64x64, batch %d' % args.batch,
+                'bound': 'mfma', 'achieved': fl / tf / 1e12, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': fl / tf / 1e12 / FP32_PEAK_TFLOPS, 'traffic': None, 'launch_ms': tf * 1e3,
+                'flops_per_launch': fl,
+                'wgrad': {'kernel': 'k_wgrad (hg_conv2d_wgrad), same layer', 'achieved': fl / tw / 1e12,
+                          'frac': fl / tw / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': tw * 1e3},
+                'generator_3x3_layers': {'flops_per_pass': tot[0],
+                                         'fwd_tflops': tot[0] / tot[1] / 1e12, 'dgrad_tflops': tot[0] / tot[2] / 1e12,
+                                         'wgrad_tflops': tot[0] / tot[3] / 1e12,
+                                         'fwd_ms': tot[1] * 1e3, 'dgrad_ms': tot[2] * 1e3, 'wgrad_ms': tot[3] * 1e3},
+                'hist': hist_roof}
+    else:
+        roof = hist_roof
 
     if rank == 0:
-        ach = work['flops_bwd'] / t_bwd / 1e12
         out = {
             'metric': METRIC, 'value': units * world * args.steps / dt, 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': info,
-            'roofline': {'kernel': 'k_hist_bwd', 'bound': 'mfma', 'achieved': ach, 'peak': FP32_PEAK_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': ach / FP32_PEAK_TFLOPS, 'traffic': None,
-                         'launch_ms': t_bwd * 1e3,
-                         'fwd': {'kernel': 'k_hist_fwd', 'achieved': work['flops_fwd'] / t_fwd / 1e12,
-                                 'frac': work['flops_fwd'] / t_fwd / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': t_fwd * 1e3}},
+            'roofline': roof,
             'hist_hbm_gbps_algorithmic': (work['bytes_fwd'] + work['bytes_bwd']) / (t_fwd + t_bwd) / 1e9,
             'hist_hbm_frac_of_peak': (work['bytes_fwd'] + work['bytes_bwd']) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBPS,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args)
+            out['cpu_baseline'] = cpu_baseline_train(args) if args.workload == 'train' else cpu_baseline(args)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -113,8 +113,10 @@ def conv_fwd_packed(x, wt, N, ksize, stride=1, iscale=None, oscale=None, bias=No
     B, K, H, W = x.shape
     with torch.cuda.device(x.device):
         out = torch.empty((B, N, _out_size(H, stride), _out_size(W, stride)), dtype=torch.float32, device=x.device)
+        nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, stride, 0)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
         check(lib.hg_conv2d_fwd(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(iscale), _ptr(oscale), _ptr(bias),
-                                B, K, N, H, W, ksize, stride, _st(x)), 'hg_conv2d_fwd')
+                                B, K, N, H, W, ksize, stride, _ptr(ws), nb, _st(x)), 'hg_conv2d_fwd')
     return out
 
 
@@ -123,8 +125,10 @@ def conv_dgrad_packed(g, wt, N, H, W, ksize, stride=1, iscale=None, oscale=None)
     B, K = g.shape[:2]
     with torch.cuda.device(g.device):
         gin = torch.empty((B, N, H, W), dtype=torch.float32, device=g.device)
+        nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, stride, 1)
+        ws = torch.empty(nb, dtype=torch.uint8, device=g.device) if nb else None
         check(lib.hg_conv2d_dgrad(g.data_ptr(), wt.data_ptr(), gin.data_ptr(), _ptr(iscale), _ptr(oscale),
-                                  B, K, N, H, W, ksize, stride, _st(g)), 'hg_conv2d_dgrad')
+                                  B, K, N, H, W, ksize, stride, _ptr(ws), nb, _st(g)), 'hg_conv2d_dgrad')
     return gin
 
 

@@ -46,6 +46,8 @@ struct ConvArgs {
   int os, oy, ox;
   int toff[9];     // LDS offset of tap t inside the halo tile
   int ntx, wrow0, wrow_dy, wrow_dx;  // packed-weight row of tap t = wrow0 + (t / ntx)*wrow_dy + (t % ntx)*wrow_dx
+  int ksplit;      // > 1: blockIdx.z handles a K range and writes raw partial sums to slab[z] (out layout)
+  float *slab;
   Geom g;
 };
 
@@ -135,7 +137,10 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
 
   float xr[NH];
   f32x4 wr[NW];
-  const int nchunks = (K + KC - 1) / KC;
+  const int nchunks_all = (K + KC - 1) / KC;
+  const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;   // chunks per K split
+  const int c_begin = blockIdx.z * cps;
+  const int nchunks = c_begin + cps < nchunks_all ? c_begin + cps : nchunks_all;
   const int HWi = Hi * Wi;
 
   auto prefetch = [&](int c) __attribute__((always_inline)) {
@@ -166,8 +171,8 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
     }
   };
 
-  for (int c = -1; c < nchunks; ++c) {
-    if (c >= 0) {
+  for (int c = c_begin - 1; c < nchunks; ++c) {
+    if (c >= c_begin) {
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < NH; ++i) {
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
       __syncthreads();
     }
     if (c + 1 < nchunks) prefetch(c + 1);
-    if (c < 0) continue;
+    if (c < c_begin) continue;
 
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
@@ -211,7 +216,8 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
     const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
     const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
     if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
-    float *ob = a.out + ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
+    const size_t pofs = ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
+    float *ob = (a.ksplit > 1 ? a.slab + (size_t)blockIdx.z * a.B * N * HWo : a.out) + pofs;
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
 #pragma unroll
@@ -219,12 +225,28 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
         const int ch = n0 + (wc * TC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (ch < N) {
           float v = acc[i][j][r];
-          if (a.oscale) v *= a.oscale[b * N + ch];
-          if (a.bias) v += a.bias[ch];
+          if (a.ksplit == 1) {   // split-K partials are scaled / biased by k_splitk_reduce
+            if (a.oscale) v *= a.oscale[b * N + ch];
+            if (a.bias) v += a.bias[ch];
+          }
           ob[(size_t)ch * HWo] = v;
         }
       }
     }
+  }
+}
+
+// out[b][n][p] = oscale[b][n] * sum_z slab[z][b][n][p] + bias[n]   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__ slab, float *__restrict__ out,
+                                                       const float *__restrict__ oscale, const float *__restrict__ bias,
+                                                       long long total, int HWo, int N, int ksplit) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    float v = 0.f;
+    for (int z = 0; z < ksplit; ++z) v += slab[(size_t)z * total + i];
+    const long long bn = i / HWo;
+    if (oscale) v *= oscale[bn];
+    if (bias) v += bias[bn % N];
+    out[i] = v;
   }
 }
 
@@ -489,8 +511,46 @@ struct Taps {
   int n, ntx, dy[9], dx[9], w[9];   // ntx = taps per row of the (rows x ntx) tap grid
 };
 
+// tile shape + K split of one k_conv launch
+enum ConvTile { TILE_32x256, TILE_64x256, TILE_128x128, TILE_64x64 };
+struct ConvPlan {
+  ConvTile tile;
+  int ksplit;
+};
+
+// Pick the largest tile that still gives >= ~1.5 blocks per CU.  Wide tiles need wide rows (the staging-register
+// bound R16 in k_conv): 256-pixel tiles Wc > 8, 128-pixel tiles Wc > 4.  Launches that cannot fill the chip with
+// output tiles (few pixels, many channels: the 2x2 ... 8x8 maps) split the reduction over K into slabs.
+ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool have_ws) {
+  const long long pix = (long long)B * Hc * Wc;
+  auto blocks = [&](int nb, int mb) { return ((N + nb - 1) / nb) * ((pix + mb - 1) / mb); };
+  const bool wide256 = Wc > 8 && Hc > 8, wide128 = Wc > 4 && Hc > 4;
+  ConvPlan p;
+  p.ksplit = 1;
+  if (N <= 32 && wide256) { p.tile = TILE_32x256; return p; }
+  if (N <= 64 && wide256 && blocks(64, 256) >= 384) { p.tile = TILE_64x256; return p; }
+  if (N > 64 && wide128 && blocks(128, 128) >= 384) { p.tile = TILE_128x128; return p; }
+  p.tile = TILE_64x64;
+  // pixel tiles of the 64x64 shape: images are grouped when the map is smaller than the tile
+  const int tw = Wc <= 2 && IS == 1 ? 2 : (Wc <= 4 ? 4 : (Wc <= 8 ? 8 : (Wc <= 16 ? 16 : 32)));
+  int th = Hc <= 2 && IS == 1 ? 2 : (Hc <= 4 ? 4 : (Hc <= 8 ? 8 : (Hc <= 16 ? 16 : 32)));
+  if (th > 64 / tw) th = 64 / tw;
+  const int ni = 64 / (tw * th);
+  const long long nblk = (long long)((Wc + tw - 1) / tw) * ((Hc + th - 1) / th) * ((B + ni - 1) / ni) * ((N + 63) / 64);
+  const int kc = IS == 2 ? 8 : 16, nchunks = (K + kc - 1) / kc;
+  if (have_ws && os == 1 && nblk < 256 && nchunks >= 8) {
+    int ks = (int)((512 + nblk - 1) / nblk);
+    if (ks > nchunks / 4) ks = nchunks / 4;
+    if (ks > 32) ks = 32;
+    if (ks > 1) p.ksplit = ks;
+  }
+  return p;
+}
+
+inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st);
+
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM = false>
-int launch_conv(ConvArgs a, const Taps &tp, hipStream_t st) {
+int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t st) {
   constexpr int NB = WC * TC * 32, MB = WP * TP * 32, NT = WC * WP * 64;
   int lo_y = 0, hi_y = 0, lo_x = 0, hi_x = 0;
   for (int t = 0; t < TAPS; ++t) {
@@ -504,31 +564,48 @@ int launch_conv(ConvArgs a, const Taps &tp, hipStream_t st) {
   a.wrow0 = tp.w[0] * a.Kp;
   a.wrow_dx = tp.ntx > 1 ? (tp.w[1] - tp.w[0]) * a.Kp : 0;
   a.wrow_dy = TAPS > tp.ntx ? (tp.w[tp.ntx] - tp.w[0]) * a.Kp : 0;
+  a.ksplit = ksplit;
   const size_t lds = ((size_t)TAPS * KC * NB + (size_t)KC * a.g.CHS) * sizeof(float);
   auto kern = k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  const dim3 grid((unsigned)(a.g.tiles_x * a.g.tiles_y * a.g.groups), (unsigned)((a.N + NB - 1) / NB));
+  const dim3 grid((unsigned)(a.g.tiles_x * a.g.tiles_y * a.g.groups), (unsigned)((a.N + NB - 1) / NB), (unsigned)ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);
+  HG_LAUNCH_CHECK();
+  if (ksplit > 1 && reduce) return launch_splitk_reduce(a, ksplit, st);
+  return HG_OK;
+}
+
+inline size_t conv_ws_bytes(const ConvPlan &p, int B, int N, int Ho, int Wo) {
+  return p.ksplit > 1 ? (size_t)p.ksplit * B * N * Ho * Wo * sizeof(float) : 0;
+}
+
+inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st) {
+  const long long total = (long long)a.B * a.N * a.Ho * a.Wo;
+  long long nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)nb), dim3(256), 0, st, a.slab, a.out, a.oscale, a.bias, total,
+                     a.Ho * a.Wo, a.N, ksplit);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
 
+// force_ksplit > 0: the caller fixed the K split (and reduces the slabs itself); the 64x64 tile is used
 template <int TAPS, int IS>
-int dispatch_conv(const ConvArgs &a, const Taps &tp, hipStream_t st) {
+int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStream_t st, int force_ksplit = 0) {
   constexpr int KC = IS == 2 ? 4 : 8;
-  const long long pix = (long long)a.B * a.Hc * a.Wc;
-  const int N = a.N;
-  // blocks each tile shape would launch; pick the largest tile that still gives >= ~1.5 blocks per CU.
-  // Wide tiles need wide rows (the staging-register bound R16 in k_conv): 256-pixel tiles Wc > 8, 128-pixel Wc > 4.
-  auto blocks = [&](int nb, int mb) { return ((N + nb - 1) / nb) * ((pix + mb - 1) / mb); };
-  const bool wide256 = a.Wc > 8 && a.Hc > 8, wide128 = a.Wc > 4 && a.Hc > 4;
-  if (N <= 32 && wide256) return launch_conv<1, 4, 1, 2, TAPS, KC, IS>(a, tp, st);                       // 32 ch x 256 px
-  if (N <= 64 && wide256 && blocks(64, 256) >= 384) return launch_conv<1, 4, 2, 2, TAPS, KC, IS>(a, tp, st);  // 64 ch x 256 px
-  if (N > 64 && wide128 && blocks(128, 128) >= 384) return launch_conv<2, 2, 2, 2, TAPS, KC, IS>(a, tp, st);  // 128 ch x 128 px
-  return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, IS == 1>(a, tp, st);                                   // 64 ch x 64 px
+  a.slab = (float *)ws;
+  if (force_ksplit > 0) return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, IS == 1>(a, tp, force_ksplit, false, st);
+  ConvPlan p = plan_conv(a.B, a.K, a.N, a.Hc, a.Wc, IS, a.os, ws != nullptr);
+  if (conv_ws_bytes(p, a.B, a.N, a.Ho, a.Wo) > ws_bytes) p.ksplit = 1;   // too little scratch: no K split
+  switch (p.tile) {
+    case TILE_32x256: return launch_conv<1, 4, 1, 2, TAPS, KC, IS>(a, tp, 1, true, st);
+    case TILE_64x256: return launch_conv<1, 4, 2, 2, TAPS, KC, IS>(a, tp, 1, true, st);
+    case TILE_128x128: return launch_conv<2, 2, 2, 2, TAPS, KC, IS>(a, tp, 1, true, st);
+    default: return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, IS == 1>(a, tp, p.ksplit, true, st);
+  }
 }
 
 struct WgradPlan {
@@ -655,9 +732,24 @@ int hg_conv_pack_weights(const float *w, float *wt, int32_t Co, int32_t Ci, int3
   return HG_OK;
 }
 
+size_t hg_conv2d_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride,
+                                 int32_t dgrad) {
+  if (!conv_args_ok(B, K, N, Hi, Wi, ksize, stride)) return 0;
+  if (dgrad) {
+    if (stride != 1) {
+      if (Hi == 1 || Wi == 1) return 0;
+      const ConvPlan p = plan_conv(B, K, N, (Hi + 1) / 2, (Wi + 1) / 2, 1, 1, true);
+      return p.tile == TILE_64x64 && p.ksplit > 1 ? (size_t)p.ksplit * B * N * Hi * Wi * sizeof(float) : 0;
+    }
+    return conv_ws_bytes(plan_conv(B, K, N, Hi, Wi, 1, 1, true), B, N, Hi, Wi);
+  }
+  const int Ho = out_size(Hi, stride), Wo = out_size(Wi, stride);
+  return conv_ws_bytes(plan_conv(B, K, N, Ho, Wo, stride, 1, true), B, N, Ho, Wo);
+}
+
 int hg_conv2d_fwd(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
                   const float *bias, int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
-                  int32_t stride, void *stream) {
+                  int32_t stride, void *workspace, size_t workspace_bytes, void *stream) {
   if (!in || !wt || !out || !conv_args_ok(B, K, N, Hi, Wi, ksize, stride)) return HG_EINVAL;
   if (!fits_i32(B, K, N, Hi, Wi)) return HG_EUNSUPPORTED;
   ConvArgs a;
@@ -670,16 +762,17 @@ int hg_conv2d_fwd(const float *in, const float *wt, float *out, const float *isc
   hipStream_t st = (hipStream_t)stream;
   if (ksize == 1) {
     tp.n = 1; tp.ntx = 1; tp.dy[0] = tp.dx[0] = 0; tp.w[0] = 0;
-    return dispatch_conv<1, 1>(a, tp, st);
+    return dispatch_conv<1, 1>(a, tp, workspace, workspace_bytes, st);
   }
   tp.n = 9; tp.ntx = 3;
   for (int t = 0; t < 9; ++t) { tp.dy[t] = t / 3 - 1; tp.dx[t] = t % 3 - 1; tp.w[t] = t; }
-  return stride == 1 ? dispatch_conv<9, 1>(a, tp, st) : dispatch_conv<9, 2>(a, tp, st);
+  return stride == 1 ? dispatch_conv<9, 1>(a, tp, workspace, workspace_bytes, st)
+                     : dispatch_conv<9, 2>(a, tp, workspace, workspace_bytes, st);
 }
 
 int hg_conv2d_dgrad(const float *gout, const float *wt, float *gin, const float *iscale, const float *oscale,
                     int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride,
-                    void *stream) {
+                    void *workspace, size_t workspace_bytes, void *stream) {
   if (!gout || !wt || !gin || !conv_args_ok(B, K, N, Hi, Wi, ksize, stride)) return HG_EINVAL;
   if (!fits_i32(B, K, N, Hi, Wi)) return HG_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -694,15 +787,24 @@ int hg_conv2d_dgrad(const float *gout, const float *wt, float *gin, const float 
     a.Hc = Hi; a.Wc = Wi; a.os = 1; a.oy = a.ox = 0;
     if (ksize == 1) {
       tp.n = 1; tp.ntx = 1; tp.dy[0] = tp.dx[0] = 0; tp.w[0] = 0;
-      return dispatch_conv<1, 1>(a, tp, st);
+      return dispatch_conv<1, 1>(a, tp, workspace, workspace_bytes, st);
     }
     tp.n = 9; tp.ntx = 3;
     for (int t = 0; t < 9; ++t) { tp.dy[t] = t / 3 - 1; tp.dx[t] = t % 3 - 1; tp.w[t] = t; }
-    return dispatch_conv<9, 1>(a, tp, st);
+    return dispatch_conv<9, 1>(a, tp, workspace, workspace_bytes, st);
   }
   // stride 2: gin[2y+pY, 2x+pX] = sum over the taps (dy,dx) with dy == pY+1, dx == pX+1 (mod 2) of
   //           gout[y + (pY+1-dy)/2, x + (pX+1-dx)/2] * W[.,.,dy,dx];  the dgrad packing stores W[dy,dx] at tap 8-(3dy+dx)
   a.os = 2;
+  // K split decided once for the four parity launches (they fill disjoint pixels of the same slabs)
+  int ksplit = 0;
+  {
+    ConvPlan p = plan_conv(B, K, N, (Hi + 1) / 2, (Wi + 1) / 2, 1, 1, workspace != nullptr);
+    // (a 1-pixel-wide image has empty parity classes, whose slab pixels would never be written: no split then)
+    if (Hi > 1 && Wi > 1 && p.tile == TILE_64x64 && p.ksplit > 1 &&
+        (size_t)p.ksplit * B * N * Hi * Wi * sizeof(float) <= workspace_bytes)
+      ksplit = p.ksplit;
+  }
   for (int pY = 0; pY < 2; ++pY)
     for (int pX = 0; pX < 2; ++pX) {
       a.Hc = (Hi - pY + 1) / 2; a.Wc = (Wi - pX + 1) / 2;
@@ -716,11 +818,15 @@ int hg_conv2d_dgrad(const float *gout, const float *wt, float *gin, const float 
             ++tp.n;
           }
       int rc;
-      if (tp.n == 1) rc = dispatch_conv<1, 1>(a, tp, st);
-      else if (tp.n == 2) rc = dispatch_conv<2, 1>(a, tp, st);
-      else rc = dispatch_conv<4, 1>(a, tp, st);
+      if (tp.n == 1) rc = dispatch_conv<1, 1>(a, tp, workspace, workspace_bytes, st, ksplit);
+      else if (tp.n == 2) rc = dispatch_conv<2, 1>(a, tp, workspace, workspace_bytes, st, ksplit);
+      else rc = dispatch_conv<4, 1>(a, tp, workspace, workspace_bytes, st, ksplit);
       if (rc) return rc;
     }
+  if (ksplit > 1) {
+    a.slab = (float *)workspace;
+    return launch_splitk_reduce(a, ksplit, st);
+  }
   return HG_OK;
 }
 

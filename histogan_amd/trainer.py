@@ -358,8 +358,11 @@ class Trainer():
             with torch.no_grad():   # the reference detaches this output; no graph is needed
                 w_styles, h_w_space = self._w_and_hw(style, hist_batch)
                 generated_images = GAN.G(w_styles, h_w_space, noise)
-            fake_output, fake_q_loss = Disc(generated_images)
-            real_output, real_q_loss = Disc(image_batch)
+            # one discriminator pass over [fake; real] (samples are independent: same values as two passes,
+            # :911-912, but twice the pixels per launch on the small maps)
+            both_output, both_q_loss = Disc(torch.cat((generated_images, image_batch), dim=0))
+            fake_output, real_output = both_output[:batch_size], both_output[batch_size:]
+            fake_q_loss = real_q_loss = both_q_loss * 0.5
             divergence = (F.relu(1 + real_output) + F.relu(1 - fake_output)).mean()
             quantize_loss = (fake_q_loss + real_q_loss).mean()
             q_val = quantize_loss.detach()

@@ -39,7 +39,13 @@ int hg_conv_pack_weights(const float *w, float *wt, int32_t Co, int32_t Ci, int3
  *   iscale (B,K), oscale (B,N), bias (N): each may be NULL (= 1, 1, 0)   (iscale = style+1, oscale = demod). */
 int hg_conv2d_fwd(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
                   const float *bias, int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
-                  int32_t stride, void *stream);
+                  int32_t stride, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Scratch for hg_conv2d_fwd (dgrad = 0) / hg_conv2d_dgrad (dgrad = 1) with the same B,K,N,Hi,Wi,ksize,stride:
+ * launches with few output pixels and many channels (the 2x2 ... 8x8 maps) split the reduction over K into
+ * slabs that a second kernel sums in fixed order.  0 = none needed; workspace may also be NULL (no K split). */
+size_t hg_conv2d_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
+                                 int32_t stride, int32_t dgrad);
 
 /* Data gradient of that convolution:  gin (B,N,Hi,Wi) <- gout (B,K,Ho,Wo), K = the convolution's OUTPUT
  * channels, N = its INPUT channels, (Hi,Wi) = the size of the convolution's input; wt packed with
@@ -47,7 +53,7 @@ int hg_conv2d_fwd(const float *in, const float *wt, float *out, const float *isc
  * Stride 2 runs as four launches (one per parity class of the output pixel). */
 int hg_conv2d_dgrad(const float *gout, const float *wt, float *gin, const float *iscale, const float *oscale,
                     int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride,
-                    void *stream);
+                    void *workspace, size_t workspace_bytes, void *stream);
 
 /* Weight gradient: gw[n,k,dy,dx] = sum_{b,y,x} gscale[b,n]*gout[b,n,y,x] * iscale[b,k]*in[b,k,y*stride+dy-p,x*stride+dx-p]
  *   in (B,K,Hi,Wi), gout (B,N,Ho,Wo), gw (N,K,ksize,ksize) contiguous, fully written (deterministic: split-K
