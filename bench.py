@@ -97,6 +97,17 @@ G_LAYERS = [(64, 2048, 4), (2048, 2048, 4), (2048, 1024, 8), (1024, 1024, 8), (1
             (64, 32, 256), (32, 32, 256)]
 
 
+def recorded_traffic(key):
+    """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes of exactly this
+    launch (profiles/r01_conv_pmc.md); None when no measurement is recorded for it."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
+            rec = json.load(f)[key]
+        return rec['fetch_bytes'] + rec['write_bytes']
+    except Exception:
+        return None
+
+
 def conv_kernel_times(dev, B, iters=6):
     """HIP events (torch's current stream == the stream the C ABI launches on) around hg_conv2d_fwd /
     hg_conv2d_dgrad / hg_conv2d_wgrad with preallocated buffers, for every generator 3x3 layer.
@@ -278,7 +289,8 @@ def main():
     t_fwd, t_bwd = time_kernels(min(max(args.steps, 5), 20))
     hist_roof = {'kernel': 'k_hist_bwd', 'bound': 'mfma', 'achieved': work['flops_bwd'] / t_bwd / 1e12,
                  'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': work['flops_bwd'] / t_bwd / 1e12 / FP32_PEAK_TFLOPS,
-                 'traffic': None, 'launch_ms': t_bwd * 1e3,
+                 'traffic': recorded_traffic('k_hist_bwd_c2') if (args.batch, args.size, args.bins) == (32, 256, 64) else None,
+                 'launch_ms': t_bwd * 1e3,
                  'fwd': {'kernel': 'k_hist_fwd', 'achieved': work['flops_fwd'] / t_fwd / 1e12,
                          'frac': work['flops_fwd'] / t_fwd / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': t_fwd * 1e3}}
     if args.workload == 'train':
@@ -287,8 +299,11 @@ def main():
         tot = [sum(v[i] for v in ct.values()) for i in range(4)]
         roof = {'kernel': 'k_conv<128ch x 128px tile, 3x3, stride 1> (hg_conv2d_fwd) at 256->128 ch, 64x64, batch %d' % args.batch,
                 'bound': 'mfma', 'achieved': fl / tf / 1e12, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': fl / tf / 1e12 / FP32_PEAK_TFLOPS, 'traffic': None, 'launch_ms': tf * 1e3,
-                'flops_per_launch': fl,
+                'frac': fl / tf / 1e12 / FP32_PEAK_TFLOPS,
+                'traffic': recorded_traffic('k_conv_fwd_256_128_64_b32') if args.batch == 32 else None,
+                'traffic_unit': 'bytes/launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_conv_pmc.md)',
+                'launch_ms': tf * 1e3, 'flops_per_launch': fl,
+                'algorithmic_bytes_per_launch': 4.0 * (args.batch * 256 * 64 * 64 + args.batch * 128 * 64 * 64 + 9 * 256 * 128),
                 'wgrad': {'kernel': 'k_wgrad (hg_conv2d_wgrad), same layer', 'achieved': fl / tw / 1e12,
                           'frac': fl / tw / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': tw * 1e3},
                 'generator_3x3_layers': {'flops_per_pass': tot[0],
