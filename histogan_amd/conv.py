@@ -169,7 +169,11 @@ class _Conv(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 gw = _ConvWgrad.apply(g, x, w.shape[2], ctx.stride)
             if ctx.has_bias and ctx.needs_input_grad[2]:
-                gb = g.sum(dim=(0, 2, 3))
+                if torch.is_grad_enabled():     # higher-order pass: keep the sum on the autograd tape
+                    gb = g.sum(dim=(0, 2, 3))
+                else:
+                    from .ops import channel_sum
+                    gb = channel_sum(g)
         return gx, gw, gb, None
 
 

@@ -25,6 +25,14 @@
 #include "../../include/hg_hist.h"
 #include "../../include/hg_conv.h"
 
+// tuning knobs (experiment builds: HG_CFLAGS='-DHG_CONV_MINW=3' python -m histogan_amd.build, see build.py)
+#ifndef HG_CONV_MINW
+#define HG_CONV_MINW 2   // __launch_bounds__ minimum waves per SIMD of k_conv (register budget 512 / MINW)
+#endif
+#ifndef HG_CONV_KC
+#define HG_CONV_KC 4     // input channels per K chunk of the stride-1 tiles (64x64 tile: twice that); 2/4/8 measure within 3 %
+#endif
+
 namespace {
 
 struct Geom {
@@ -58,7 +66,7 @@ __device__ __forceinline__ int fdiv(int e, float inv) {  // floor(e / d) for 0 <
 // ------------------------------------------------------------------------------------------------
 // output / data-gradient kernel
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM>
-__global__ __launch_bounds__(WC *WP * 64, 2) void k_conv(const ConvArgs a) {
+__global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvArgs a) {
   constexpr int NT = WC * WP * 64;
   constexpr int NB = WC * TC * 32;  // channels per block
   constexpr int MB = WP * TP * 32;  // pixels per block
@@ -314,7 +322,28 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
   const int himg = hrr / G::IMS, hy = (hrr % G::IMS) / G::TWp, hx = hrr % G::TWp;
   const bool hlane = hcs < HCPI;
 
+  // Prefetch loads are UNCONDITIONAL (a `valid ? load : 0` select puts an s_waitcnt right behind every load and
+  // serialises the global latency with the MFMAs -- with one block per CU nothing else hides it).  Positions outside
+  // the image / channels past the end load the nearest valid element instead (clamped coordinates: distinct, local
+  // addresses) and are zeroed when the registers are stored to LDS (static channel masks x per-chunk pixel validity).
+  const int hcs2 = hlane ? hcs : 0;                       // spare lanes mirror a position of channel slot 0
+  const int gdl = N - 1 - (n0 + gcs) > 0 ? N - 1 - (n0 + gcs) : 0;   // largest channel step that stays < N
+  const int hdl = K - 1 - (k0 + hcs2) > 0 ? K - 1 - (k0 + hcs2) : 0;
+  const int gc0 = n0 + gcs < N ? n0 + gcs : N - 1, hc0 = k0 + hcs2 < K ? k0 + hcs2 : K - 1;
+  unsigned gstat = 0;
+  unsigned long long hstat = 0;
+  static_assert(NGI <= 32 && NHI <= 64, "validity masks");
+#pragma unroll
+  for (int i = 0; i < NGI; ++i)
+    if (n0 + gcs + i * GCPI < N && (NGI * GCPI == NBW || gcs + i * GCPI < NBW)) gstat |= 1u << i;
+#pragma unroll
+  for (int i = 0; i < NHI; ++i)
+    if (hlane && k0 + hcs + i * HCPI < K && (NHI * HCPI == KBW || hcs + i * HCPI < KBW)) hstat |= 1ull << i;
+
   float gr[NGI], hr[NHI];
+  unsigned gmask = 0;
+  unsigned long long hmask = 0;
+  int pb0 = 0;   // image-group origin of the prefetched chunk (for the scale lookups at the store)
   auto prefetch = [&](int chunk) __attribute__((always_inline)) {
     int pt = chunk;
     const int tx = pt % a.tiles_x;
@@ -322,35 +351,25 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
     const int ty = pt % a.tiles_y;
     const int grp = pt / a.tiles_y;
     const int x0 = tx * G::TW, y0 = ty * G::TH, b0 = grp * G::NI;
+    pb0 = b0;
     {
       const int gx = x0 + gpx, gy = y0 + gpy, b = b0 + gpi;
       const bool ok = b < a.B && gy < Ho && gx < Wo;
-      const unsigned srow = (unsigned)(b * N + n0 + gcs);
-      const unsigned off = srow * (unsigned)HWo + (unsigned)(gy * Wo + gx);
+      const int cb = b < a.B ? b : a.B - 1, cy = gy < Ho ? gy : Ho - 1, cx = gx < Wo ? gx : Wo - 1;
+      const unsigned off = (unsigned)(cb * N + gc0) * (unsigned)HWo + (unsigned)(cy * Wo + cx);
+      gmask = ok ? gstat : 0u;
 #pragma unroll
-      for (int i = 0; i < NGI; ++i) {
-        float v = 0.f;
-        if (ok && n0 + gcs + i * GCPI < N && (NGI * GCPI == NBW || gcs + i * GCPI < NBW)) {
-          v = a.gout[off + (unsigned)(i * GCPI) * (unsigned)HWo];
-          if (a.gscale) v *= a.gscale[srow + i * GCPI];
-        }
-        gr[i] = v;
-      }
+      for (int i = 0; i < NGI; ++i) gr[i] = a.gout[off + (unsigned)(i * GCPI < gdl ? i * GCPI : gdl) * (unsigned)HWo];
     }
     {
       const int gy = y0 * IS + hy - PAD, gx = x0 * IS + hx - PAD, b = b0 + himg;
-      const bool ok = hlane && b < a.B && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi;
-      const unsigned srow = (unsigned)(b * K + k0 + hcs);
-      const unsigned off = srow * (unsigned)HWi + (unsigned)(gy * Wi + gx);
+      const bool ok = b < a.B && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi;
+      const int cb = b < a.B ? b : a.B - 1;
+      const int cy = gy < 0 ? 0 : (gy >= Hi ? Hi - 1 : gy), cx = gx < 0 ? 0 : (gx >= Wi ? Wi - 1 : gx);
+      const unsigned off = (unsigned)(cb * K + hc0) * (unsigned)HWi + (unsigned)(cy * Wi + cx);
+      hmask = ok ? hstat : 0ull;
 #pragma unroll
-      for (int i = 0; i < NHI; ++i) {
-        float v = 0.f;
-        if (ok && k0 + hcs + i * HCPI < K && (NHI * HCPI == KBW || hcs + i * HCPI < KBW)) {
-          v = a.in[off + (unsigned)(i * HCPI) * (unsigned)HWi];
-          if (a.iscale) v *= a.iscale[srow + i * HCPI];
-        }
-        hr[i] = v;
-      }
+      for (int i = 0; i < NHI; ++i) hr[i] = a.in[off + (unsigned)(i * HCPI < hdl ? i * HCPI : hdl) * (unsigned)HWi];
     }
   };
 
@@ -360,10 +379,18 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < NGI; ++i)
-        if (NGI * GCPI == NBW || gcs + i * GCPI < NBW) Gs[(gcs + i * GCPI) * GP + gp] = gr[i];
+        if (NGI * GCPI == NBW || gcs + i * GCPI < NBW) {
+          float v = (gmask >> i) & 1u ? gr[i] : 0.f;
+          if (a.gscale != nullptr && ((gmask >> i) & 1u)) v *= a.gscale[(pb0 + gpi) * N + n0 + gcs + i * GCPI];
+          Gs[(gcs + i * GCPI) * GP + gp] = v;
+        }
 #pragma unroll
       for (int i = 0; i < NHI; ++i)
-        if (hlane && (NHI * HCPI == KBW || hcs + i * HCPI < KBW)) Xs[(hcs + i * HCPI) * G::CHS + hrr] = hr[i];
+        if (hlane && (NHI * HCPI == KBW || hcs + i * HCPI < KBW)) {
+          float v = (hmask >> i) & 1ull ? hr[i] : 0.f;
+          if (a.iscale != nullptr && ((hmask >> i) & 1ull)) v *= a.iscale[(pb0 + himg) * K + k0 + hcs + i * HCPI];
+          Xs[(hcs + i * HCPI) * G::CHS + hrr] = v;
+        }
       __syncthreads();
     }
     if (chunk + a.splits < a.nchunks) prefetch(chunk + a.splits);
@@ -537,7 +564,7 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
   if (th > 64 / tw) th = 64 / tw;
   const int ni = 64 / (tw * th);
   const long long nblk = (long long)((Wc + tw - 1) / tw) * ((Hc + th - 1) / th) * ((B + ni - 1) / ni) * ((N + 63) / 64);
-  const int kc = IS == 2 ? 8 : 16, nchunks = (K + kc - 1) / kc;
+  const int kc = IS == 2 ? 8 : 2 * HG_CONV_KC, nchunks = (K + kc - 1) / kc;
   if (have_ws && os == 1 && nblk < 256 && nchunks >= 8) {
     int ks = (int)((512 + nblk - 1) / nblk);
     if (ks > nchunks / 4) ks = nchunks / 4;
@@ -595,7 +622,7 @@ inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st) {
 // force_ksplit > 0: the caller fixed the K split (and reduces the slabs itself); the 64x64 tile is used
 template <int TAPS, int IS>
 int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStream_t st, int force_ksplit = 0) {
-  constexpr int KC = IS == 2 ? 4 : 8;
+  constexpr int KC = IS == 2 ? 4 : HG_CONV_KC;
   a.slab = (float *)ws;
   if (force_ksplit > 0) return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, IS == 1>(a, tp, force_ksplit, false, st);
   ConvPlan p = plan_conv(a.B, a.K, a.N, a.Hc, a.Wc, IS, a.os, ws != nullptr);

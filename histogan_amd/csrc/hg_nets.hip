@@ -55,133 +55,242 @@ __global__ __launch_bounds__(256) void k_modulate_fwd(const float *__restrict__ 
   }
 }
 
-// one thread per SOURCE pixel: writes the 2x2 output block it anchors (polyphase: 3x3 taps -> 4 outputs)
+// Bilinear x2 (align_corners=False, edge clamp) is the separable polyphase filter
+//   out[2k] = 1/4 x[k-1] + 3/4 x[k],  out[2k+1] = 3/4 x[k] + 1/4 x[k+1]      (indices clamped to the image)
+// evaluated in aten's order ((1-lx) a + lx b along x, then along y) so that the values equal F.interpolate's.
+// One thread per source pixel: reads its 3x3 neighbourhood, writes the 2x2 output block it anchors.
 __global__ __launch_bounds__(256) void k_up2_modulate_fwd(const float *__restrict__ x, const float *__restrict__ s,
-                                                          float *__restrict__ out, int BC, int H, int W) {
-  const long long total = (long long)BC * H * W;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int l = (int)(idx % W), k = (int)((idx / W) % H);
-    const long long bc = idx / ((long long)W * H);
-    const float m = s ? s[bc] + 1.f : 1.f;
-    const float *xp = x + bc * H * W;
-    float *op = out + bc * 4LL * H * W;
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
-      const int Y = 2 * k + dy;
-      int y0, y1; float ly;
-      up2_taps(Y, H, y0, y1, ly);
-      float2 o;
-#pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
-        const int X = 2 * l + dx;
-        int x0, x1; float lx;
-        up2_taps(X, W, x0, x1, lx);
-        const float t0 = (1.f - lx) * xp[y0 * W + x0] + lx * xp[y0 * W + x1];
-        const float t1 = (1.f - lx) * xp[y1 * W + x0] + lx * xp[y1 * W + x1];
-        const float v = ((1.f - ly) * t0 + ly * t1) * m;
-        if (dx == 0) o.x = v; else o.y = v;
-      }
-      *reinterpret_cast<float2 *>(op + (long long)Y * (2 * W) + 2 * l) = o;
-    }
+                                                          float *__restrict__ out, int H, int W) {
+  const int bc = blockIdx.y;
+  const float m = s ? s[bc] + 1.f : 1.f;
+  const float *xp = x + (size_t)bc * H * W;
+  float *op = out + (size_t)bc * 4 * H * W;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < H * W; e += gridDim.x * 256) {
+    const int k = e / W, l = e - k * W;
+    const int km = k > 0 ? k - 1 : 0, kp = k < H - 1 ? k + 1 : H - 1;
+    const int lm = l > 0 ? l - 1 : 0, lp = l < W - 1 ? l + 1 : W - 1;
+    const float a00 = xp[km * W + lm], a01 = xp[km * W + l], a02 = xp[km * W + lp];
+    const float a10 = xp[k * W + lm], a11 = xp[k * W + l], a12 = xp[k * W + lp];
+    const float a20 = xp[kp * W + lm], a21 = xp[kp * W + l], a22 = xp[kp * W + lp];
+    // horizontal pass: even column 2l = (i0=l-1, lambda=.75) except l == 0 (i0=0, lambda=0); odd = (i0=l, lambda=.25)
+    const float le = l > 0 ? 0.75f : 0.f;
+    const float r0e = (1.f - le) * (l > 0 ? a00 : a01) + le * a01, r0o = 0.75f * a01 + 0.25f * a02;
+    const float r1e = (1.f - le) * (l > 0 ? a10 : a11) + le * a11, r1o = 0.75f * a11 + 0.25f * a12;
+    const float r2e = (1.f - le) * (l > 0 ? a20 : a21) + le * a21, r2o = 0.75f * a21 + 0.25f * a22;
+    const float ke = k > 0 ? 0.75f : 0.f;
+    float2 top, bot;
+    top.x = ((1.f - ke) * (k > 0 ? r0e : r1e) + ke * r1e) * m;
+    top.y = ((1.f - ke) * (k > 0 ? r0o : r1o) + ke * r1o) * m;
+    bot.x = (0.75f * r1e + 0.25f * r2e) * m;
+    bot.y = (0.75f * r1o + 0.25f * r2o) * m;
+    *reinterpret_cast<float2 *>(op + (size_t)(2 * k) * (2 * W) + 2 * l) = top;
+    *reinterpret_cast<float2 *>(op + (size_t)(2 * k + 1) * (2 * W) + 2 * l) = bot;
   }
 }
 
-// one block per (b,c) plane: t = up^T(g) (or g), gx = t*(s+1), gs = sum x*t
-template <int NT>
-__global__ __launch_bounds__(NT) void k_modulate_bwd(const float *__restrict__ gout, const float *__restrict__ x,
-                                                     const float *__restrict__ s, float *__restrict__ gx,
-                                                     float *__restrict__ gs, int H, int W, int upsample) {
+// adjoint weight of source index k in output index Y (one axis): Y in {2k-1, 2k, 2k+1, 2k+2}
+__device__ __forceinline__ float up2_adj_w(int d /* Y - 2k + 1 in 0..3 */, int k, int H) {
+  // interior: 1/4, 3/4, 3/4, 1/4; the clamped edges fold the missing neighbour's share back in
+  float w = (d == 0 || d == 3) ? 0.25f : 0.75f;
+  if (k == 0 && d == 1) w = 1.f;
+  if (k == H - 1 && d == 2) w = 1.f;
+  return w;
+}
+
+// t = up^T(g) (or g), gx = t*(s+1), gs = sum x*t.  grid = (chunks, planes): partial sums per chunk, summed in
+// fixed order by k_plane_sum_finish.
+template <int UP>
+__global__ __launch_bounds__(256) void k_modulate_bwd(const float *__restrict__ gout, const float *__restrict__ x,
+                                                      const float *__restrict__ s, float *__restrict__ gx,
+                                                      float *__restrict__ part, int H, int W) {
   __shared__ float sm[4];
-  const long long bc = blockIdx.x;
+  const int bc = blockIdx.y;
   const float m = s ? s[bc] + 1.f : 1.f;
-  const float *xp = x + bc * H * W;
-  float *gxp = gx + bc * H * W;
+  const float *xp = x + (size_t)bc * H * W;
+  float *gxp = gx + (size_t)bc * H * W;
   float acc = 0.f;
-  if (!upsample) {
-    const float *gp = gout + bc * H * W;
-    for (int e = threadIdx.x; e < H * W; e += NT) {
-      const float t = gp[e];
-      gxp[e] = t * m;
-      acc = fmaf(xp[e], t, acc);
+  if (UP == 0) {
+    const float *gp = gout + (size_t)bc * H * W;
+    if (((H * W) & 3) == 0) {
+      for (int e = blockIdx.x * 256 + threadIdx.x; e < H * W / 4; e += gridDim.x * 256) {
+        const float4 t = reinterpret_cast<const float4 *>(gp)[e];
+        const float4 xv = reinterpret_cast<const float4 *>(xp)[e];
+        float4 o;
+        o.x = t.x * m; o.y = t.y * m; o.z = t.z * m; o.w = t.w * m;
+        reinterpret_cast<float4 *>(gxp)[e] = o;
+        acc += (xv.x * t.x + xv.y * t.y) + (xv.z * t.z + xv.w * t.w);
+      }
+    } else {
+      for (int e = blockIdx.x * 256 + threadIdx.x; e < H * W; e += gridDim.x * 256) {
+        const float t = gp[e];
+        gxp[e] = t * m;
+        acc = fmaf(xp[e], t, acc);
+      }
     }
   } else {
     const int H2 = 2 * H, W2 = 2 * W;
-    const float *gp = gout + bc * (long long)H2 * W2;
-    for (int e = threadIdx.x; e < H * W; e += NT) {
+    const float *gp = gout + (size_t)bc * H2 * W2;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < H * W; e += gridDim.x * 256) {
       const int k = e / W, l = e - k * W;
       float t = 0.f;
 #pragma unroll
-      for (int dy = -1; dy <= 2; ++dy) {
-        const int Y = 2 * k + dy;
+      for (int dy = 0; dy < 4; ++dy) {
+        const int Y = 2 * k - 1 + dy;
         if (Y < 0 || Y >= H2) continue;
-        const float wy = up2_w(Y, k, H);
-        if (wy == 0.f) continue;
+        const float wy = up2_adj_w(dy, k, H);
+        const float *row = gp + (size_t)Y * W2;
+        float r = 0.f;
 #pragma unroll
-        for (int dx = -1; dx <= 2; ++dx) {
-          const int X = 2 * l + dx;
+        for (int dx = 0; dx < 4; ++dx) {
+          const int X = 2 * l - 1 + dx;
           if (X < 0 || X >= W2) continue;
-          const float wx = up2_w(X, l, W);
-          t = fmaf(wy * wx, gp[(long long)Y * W2 + X], t);
+          r = fmaf(up2_adj_w(dx, l, W), row[X], r);
         }
+        t = fmaf(wy, r, t);
       }
       gxp[e] = t * m;
       acc = fmaf(xp[e], t, acc);
     }
   }
-  if (gs) {
-    acc = block_sum<NT>(acc, sm);
-    if (threadIdx.x == 0) gs[bc] = acc;
+  if (part) {
+    acc = block_sum<256>(acc, sm);
+    if (threadIdx.x == 0) part[(size_t)bc * gridDim.x + blockIdx.x] = acc;
   }
+}
+
+// out[plane] = sum_c part[plane][c]   (fixed order)
+__global__ __launch_bounds__(256) void k_plane_sum_finish(const float *__restrict__ part, float *__restrict__ out,
+                                                          int planes, int chunks) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= planes) return;
+  float v = 0.f;
+  for (int c = 0; c < chunks; ++c) v += part[(size_t)p * chunks + c];
+  out[p] = v;
 }
 
 // ---- epilogue -------------------------------------------------------------------------------
 // nzt = the noise image already transposed: nzt[b][i][j] = inoise[b][j][i][0]  (S x S per sample)
+// grid = (chunks, B*O); 4 pixels per thread when H % 4 == 0
 __global__ __launch_bounds__(256) void k_dnl_fwd(const float *__restrict__ conv, const float *__restrict__ d,
                                                  const float *__restrict__ nzt, const float *__restrict__ wn,
-                                                 const float *__restrict__ bn, float *__restrict__ out, int B, int O,
+                                                 const float *__restrict__ bn, float *__restrict__ out, int O,
                                                  int H, int S) {
+  const int bo = blockIdx.y, o = bo % O, b = bo / O;
   const int hw = H * H;
-  const long long total = (long long)B * O * hw;
-  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-    const int e = (int)(idx % hw);
-    const long long bo = idx / hw;
-    const int o = (int)(bo % O), b = (int)(bo / O);
-    const int i = e / H, j = e - i * H;
-    const float dd = d ? d[bo] : 1.f;
-    const float v = fmaf(conv[idx], dd, fmaf(wn[o], nzt[((long long)b * S + i) * S + j], bn[o]));
-    out[idx] = v > 0.f ? v : 0.2f * v;
+  const float dd = d ? d[bo] : 1.f, w = wn[o], bb = bn[o];
+  const float *cp = conv + (size_t)bo * hw;
+  float *op = out + (size_t)bo * hw;
+  const float *np = nzt + (size_t)b * S * S;
+  if ((H & 3) == 0) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < hw / 4; e += gridDim.x * 256) {
+      const int i = (e * 4) / H, j = e * 4 - i * H;
+      const float4 c = reinterpret_cast<const float4 *>(cp)[e];
+      const float4 n = *reinterpret_cast<const float4 *>(np + (size_t)i * S + j);   // S % 4 == 0 too (S >= H, pow 2)
+      float4 v;
+      v.x = fmaf(c.x, dd, fmaf(w, n.x, bb)); v.y = fmaf(c.y, dd, fmaf(w, n.y, bb));
+      v.z = fmaf(c.z, dd, fmaf(w, n.z, bb)); v.w = fmaf(c.w, dd, fmaf(w, n.w, bb));
+      v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
+      v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
+      reinterpret_cast<float4 *>(op)[e] = v;
+    }
+  } else {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < hw; e += gridDim.x * 256) {
+      const int i = e / H, j = e - i * H;
+      const float v = fmaf(cp[e], dd, fmaf(w, np[(size_t)i * S + j], bb));
+      op[e] = v > 0.f ? v : 0.2f * v;
+    }
   }
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT) void k_dnl_bwd(const float *__restrict__ gout, const float *__restrict__ out,
-                                                const float *__restrict__ conv, const float *__restrict__ d,
-                                                const float *__restrict__ nzt, float *__restrict__ gconv,
-                                                float *__restrict__ gd, float *__restrict__ gwn_part,
-                                                float *__restrict__ gbn_part, int O, int H, int S) {
+// m = gout * lrelu'(out): gconv = m*d; partial sums of m*conv, m*nzt, m per (chunk, plane)
+__global__ __launch_bounds__(256) void k_dnl_bwd(const float *__restrict__ gout, const float *__restrict__ out,
+                                                 const float *__restrict__ conv, const float *__restrict__ d,
+                                                 const float *__restrict__ nzt, float *__restrict__ gconv,
+                                                 float *__restrict__ part /* [3][planes][chunks] */, int O, int H, int S) {
   __shared__ float sm[4];
-  const long long bo = blockIdx.x;
-  const int b = (int)(bo / O);
+  const int bo = blockIdx.y, b = bo / O;
   const int hw = H * H;
   const float dd = d ? d[bo] : 1.f;
-  const long long base = bo * hw;
+  const size_t base = (size_t)bo * hw;
+  const float *np = nzt + (size_t)b * S * S;
   float a_d = 0.f, a_w = 0.f, a_b = 0.f;
-  for (int e = threadIdx.x; e < hw; e += NT) {
-    const float m = gout[base + e] * (out[base + e] > 0.f ? 1.f : 0.2f);
-    gconv[base + e] = m * dd;
-    const int i = e / H, j = e - i * H;
-    a_d = fmaf(m, conv[base + e], a_d);
-    a_w = fmaf(m, nzt[((long long)b * S + i) * S + j], a_w);
-    a_b += m;
+  if ((H & 3) == 0 && (S & 3) == 0) {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < hw / 4; e += gridDim.x * 256) {
+      const int i = (e * 4) / H, j = e * 4 - i * H;
+      const float4 g = reinterpret_cast<const float4 *>(gout + base)[e];
+      const float4 o = reinterpret_cast<const float4 *>(out + base)[e];
+      const float4 c = reinterpret_cast<const float4 *>(conv + base)[e];
+      const float4 n = *reinterpret_cast<const float4 *>(np + (size_t)i * S + j);
+      float4 m;
+      m.x = g.x * (o.x > 0.f ? 1.f : 0.2f); m.y = g.y * (o.y > 0.f ? 1.f : 0.2f);
+      m.z = g.z * (o.z > 0.f ? 1.f : 0.2f); m.w = g.w * (o.w > 0.f ? 1.f : 0.2f);
+      float4 r;
+      r.x = m.x * dd; r.y = m.y * dd; r.z = m.z * dd; r.w = m.w * dd;
+      reinterpret_cast<float4 *>(gconv + base)[e] = r;
+      a_d += (m.x * c.x + m.y * c.y) + (m.z * c.z + m.w * c.w);
+      a_w += (m.x * n.x + m.y * n.y) + (m.z * n.z + m.w * n.w);
+      a_b += (m.x + m.y) + (m.z + m.w);
+    }
+  } else {
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < hw; e += gridDim.x * 256) {
+      const float m = gout[base + e] * (out[base + e] > 0.f ? 1.f : 0.2f);
+      gconv[base + e] = m * dd;
+      const int i = e / H, j = e - i * H;
+      a_d = fmaf(m, conv[base + e], a_d);
+      a_w = fmaf(m, np[(size_t)i * S + j], a_w);
+      a_b += m;
+    }
   }
-  a_d = block_sum<NT>(a_d, sm);
-  a_w = block_sum<NT>(a_w, sm);
-  a_b = block_sum<NT>(a_b, sm);
+  a_d = block_sum<256>(a_d, sm);
+  a_w = block_sum<256>(a_w, sm);
+  a_b = block_sum<256>(a_b, sm);
   if (threadIdx.x == 0) {
-    if (gd) gd[bo] = a_d;
-    gwn_part[bo] = a_w;
-    gbn_part[bo] = a_b;
+    const size_t planes = gridDim.y, idx = (size_t)bo * gridDim.x + blockIdx.x;
+    part[idx] = a_d;
+    part[planes * gridDim.x + idx] = a_w;
+    part[2 * planes * gridDim.x + idx] = a_b;
   }
+}
+
+// gd / gwn_part / gbn_part [plane] = sum over chunks of the three partial arrays (fixed order)
+__global__ __launch_bounds__(256) void k_dnl_bwd_finish(const float *__restrict__ part, float *__restrict__ gd,
+                                                        float *__restrict__ gw, float *__restrict__ gb, int planes,
+                                                        int chunks) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= planes) return;
+  float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+  for (int c = 0; c < chunks; ++c) {
+    v0 += part[(size_t)p * chunks + c];
+    v1 += part[(size_t)planes * chunks + (size_t)p * chunks + c];
+    v2 += part[2 * (size_t)planes * chunks + (size_t)p * chunks + c];
+  }
+  if (gd) gd[p] = v0;
+  gw[p] = v1;
+  gb[p] = v2;
+}
+
+// sum over (b, h, w) of a (B, C, HW) tensor -> out[C]  (bias gradient); grid = (chunks, C), partials + finish
+__global__ __launch_bounds__(256) void k_channel_sum(const float *__restrict__ g, float *__restrict__ part, int B, int C,
+                                                     int HW) {
+  __shared__ float sm[4];
+  const int c = blockIdx.y;
+  float acc = 0.f;
+  const long long per = (long long)B * HW;   // elements of channel c: (b, p) -> g[(b*C + c)*HW + p]
+  if ((HW & 3) == 0) {
+    const int hw4 = HW / 4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < per / 4; e += (long long)gridDim.x * 256) {
+      const long long b = e / hw4, p4 = e - b * hw4;
+      const float4 v = reinterpret_cast<const float4 *>(g + ((size_t)b * C + c) * HW)[p4];
+      acc += (v.x + v.y) + (v.z + v.w);
+    }
+  } else {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long long)gridDim.x * 256) {
+      const long long b = e / HW, p = e - b * HW;
+      acc += g[((size_t)b * C + c) * HW + p];
+    }
+  }
+  acc = block_sum<256>(acc, sm);
+  if (threadIdx.x == 0) part[(size_t)c * gridDim.x + blockIdx.x] = acc;
 }
 
 // ---- optimizer ------------------------------------------------------------------------------
@@ -216,13 +325,28 @@ inline unsigned grid_for(long long n_threads) {
 
 extern "C" {
 
+// chunks per plane for the partial-sum kernels: ~1024 blocks in total, each thread >= 4 vector iterations
+static inline int plane_chunks(long long planes, long long vec_per_plane) {
+  long long c = (1024 + planes - 1) / planes;
+  const long long cmax = (vec_per_plane + 1023) / 1024;   // >= 4 iterations of 256 threads
+  if (c > cmax) c = cmax;
+  if (c < 1) c = 1;
+  if (c > 64) c = 64;
+  return (int)c;
+}
+
+size_t hg_nets_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+  return (size_t)3 * B * C * 64 * sizeof(float);   // 3 partial arrays x planes x (<= 64 chunks)
+}
+
 int hg_modulate_fwd(const float *x, const float *s, float *out, int32_t B, int32_t C, int32_t H, int32_t W,
                     int32_t upsample, void *stream) {
   if (!x || !out || B <= 0 || C <= 0 || H <= 0 || W <= 0) return HG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (upsample) {
-    const long long total = (long long)B * C * H * W;
-    hipLaunchKernelGGL(k_up2_modulate_fwd, dim3(grid_for(total)), dim3(256), 0, st, x, s, out, B * C, H, W);
+    const int chunks = plane_chunks((long long)B * C, (long long)H * W);
+    hipLaunchKernelGGL(k_up2_modulate_fwd, dim3(chunks, B * C), dim3(256), 0, st, x, s, out, H, W);
   } else {
     if ((H * W) % 4) return HG_EUNSUPPORTED;
     const long long n4 = (long long)B * C * H * W / 4;
@@ -233,41 +357,66 @@ int hg_modulate_fwd(const float *x, const float *s, float *out, int32_t B, int32
 }
 
 int hg_modulate_bwd(const float *gout, const float *x, const float *s, float *gx, float *gs, int32_t B,
-                    int32_t C, int32_t H, int32_t W, int32_t upsample, void *stream) {
+                    int32_t C, int32_t H, int32_t W, int32_t upsample, void *workspace, size_t workspace_bytes,
+                    void *stream) {
   if (!gout || !x || !gx || B <= 0 || C <= 0 || H <= 0 || W <= 0) return HG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned planes = (unsigned)(B * C);
-  if (H * W <= 256)
-    hipLaunchKernelGGL((k_modulate_bwd<64>), dim3(planes), dim3(64), 0, st, gout, x, s, gx, gs, H, W, upsample);
+  const int planes = B * C;
+  const int chunks = plane_chunks(planes, (long long)H * W / (upsample ? 1 : 4));
+  float *part = nullptr;
+  if (gs) {
+    if (!workspace || workspace_bytes < (size_t)planes * chunks * sizeof(float)) return HG_EWORKSPACE;
+    part = (float *)workspace;
+  }
+  if (upsample)
+    hipLaunchKernelGGL((k_modulate_bwd<1>), dim3(chunks, planes), dim3(256), 0, st, gout, x, s, gx, part, H, W);
   else
-    hipLaunchKernelGGL((k_modulate_bwd<256>), dim3(planes), dim3(256), 0, st, gout, x, s, gx, gs, H, W, upsample);
+    hipLaunchKernelGGL((k_modulate_bwd<0>), dim3(chunks, planes), dim3(256), 0, st, gout, x, s, gx, part, H, W);
   HG_LAUNCH_CHECK();
+  if (gs) {
+    hipLaunchKernelGGL(k_plane_sum_finish, dim3((planes + 255) / 256), dim3(256), 0, st, part, gs, planes, chunks);
+    HG_LAUNCH_CHECK();
+  }
   return HG_OK;
 }
 
 int hg_demod_noise_lrelu_fwd(const float *conv, const float *d, const float *nzt, const float *wn, const float *bn,
                              float *out, int32_t B, int32_t O, int32_t H, int32_t S, void *stream) {
   if (!conv || !nzt || !wn || !bn || !out || B <= 0 || O <= 0 || H <= 0 || S < H) return HG_EINVAL;
-  const long long total = (long long)B * O * H * H;
-  hipLaunchKernelGGL(k_dnl_fwd, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, conv, d, nzt, wn, bn, out,
-                     B, O, H, S);
+  const int chunks = plane_chunks((long long)B * O, (long long)H * H / 4);
+  hipLaunchKernelGGL(k_dnl_fwd, dim3(chunks, B * O), dim3(256), 0, (hipStream_t)stream, conv, d, nzt, wn, bn, out, O, H, S);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
 
 int hg_demod_noise_lrelu_bwd(const float *gout, const float *out, const float *conv, const float *d,
                              const float *nzt, float *gconv, float *gd, float *gwn_part, float *gbn_part,
-                             int32_t B, int32_t O, int32_t H, int32_t S, void *stream) {
+                             int32_t B, int32_t O, int32_t H, int32_t S, void *workspace, size_t workspace_bytes,
+                             void *stream) {
   if (!gout || !out || !conv || !nzt || !gconv || !gwn_part || !gbn_part || B <= 0 || O <= 0 || H <= 0 || S < H)
     return HG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const unsigned planes = (unsigned)(B * O);
-  if (H * H <= 256)
-    hipLaunchKernelGGL((k_dnl_bwd<64>), dim3(planes), dim3(64), 0, st, gout, out, conv, d, nzt, gconv, gd, gwn_part,
-                       gbn_part, O, H, S);
-  else
-    hipLaunchKernelGGL((k_dnl_bwd<256>), dim3(planes), dim3(256), 0, st, gout, out, conv, d, nzt, gconv, gd,
-                       gwn_part, gbn_part, O, H, S);
+  const int planes = B * O;
+  const int chunks = plane_chunks(planes, (long long)H * H / 4);
+  if (!workspace || workspace_bytes < (size_t)3 * planes * chunks * sizeof(float)) return HG_EWORKSPACE;
+  float *part = (float *)workspace;
+  hipLaunchKernelGGL(k_dnl_bwd, dim3(chunks, planes), dim3(256), 0, st, gout, out, conv, d, nzt, gconv, part, O, H, S);
+  HG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_dnl_bwd_finish, dim3((planes + 255) / 256), dim3(256), 0, st, part, gd, gwn_part, gbn_part, planes,
+                     chunks);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+int hg_channel_sum(const float *g, float *out, int32_t B, int32_t C, int32_t HW, void *workspace, size_t workspace_bytes,
+                   void *stream) {
+  if (!g || !out || B <= 0 || C <= 0 || HW <= 0) return HG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = plane_chunks(C, (long long)B * HW / 4);
+  if (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(float)) return HG_EWORKSPACE;
+  hipLaunchKernelGGL(k_channel_sum, dim3(chunks, C), dim3(256), 0, st, g, (float *)workspace, B, C, HW);
+  HG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_plane_sum_finish, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)workspace, out, C, chunks);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }

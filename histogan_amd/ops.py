@@ -20,6 +20,22 @@ def _f32c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _ws(t, B, C, H, W):
+    n = lib.hg_nets_workspace_bytes(B, C, H, W)
+    return torch.empty(max(n, 4), dtype=torch.uint8, device=t.device), n
+
+
+def channel_sum(g):
+    """(B, C, H, W) -> (C): sum over batch and pixels (bias gradient), deterministic two-stage reduction."""
+    g = _f32c(g.detach())
+    B, C, H, W = g.shape
+    with torch.cuda.device(g.device):
+        out = torch.empty(C, dtype=torch.float32, device=g.device)
+        ws, n = _ws(g, B, C, H, W)
+        check(lib.hg_channel_sum(g.data_ptr(), out.data_ptr(), B, C, H * W, ws.data_ptr(), n, _st(g)), 'hg_channel_sum')
+    return out
+
+
 def _need_gpu(t, what):
     if not t.is_cuda:
         raise RuntimeError(f'{what}: tensor on {t.device}; the MI355X-native path has no CPU implementation')
@@ -49,9 +65,10 @@ class _Modulate(torch.autograd.Function):
         with torch.cuda.device(x.device):
             gx = torch.empty_like(x)
             gs = None if s is None else torch.empty_like(s)
+            ws, n = _ws(x, B, C, H, W)
             check(lib.hg_modulate_bwd(g.data_ptr(), x.data_ptr(), None if s is None else s.data_ptr(),
                                       gx.data_ptr(), None if gs is None else gs.data_ptr(), B, C, H, W,
-                                      int(ctx.upsample), _st(x)), 'hg_modulate_bwd')
+                                      int(ctx.upsample), ws.data_ptr(), n, _st(x)), 'hg_modulate_bwd')
         return gx, gs, None
 
 
@@ -96,10 +113,11 @@ class _DemodNoiseLrelu(torch.autograd.Function):
             gd = None if d is None else torch.empty_like(d)
             gw = torch.empty((B, O), dtype=torch.float32, device=conv.device)
             gb = torch.empty((B, O), dtype=torch.float32, device=conv.device)
+            ws, n = _ws(conv, B, O, H, H)
             check(lib.hg_demod_noise_lrelu_bwd(g.data_ptr(), out.data_ptr(), conv.data_ptr(),
                                                None if d is None else d.data_ptr(), nzt.data_ptr(), gconv.data_ptr(),
                                                None if gd is None else gd.data_ptr(), gw.data_ptr(), gb.data_ptr(),
-                                               B, O, H, S, _st(conv)), 'hg_demod_noise_lrelu_bwd')
+                                               B, O, H, S, ws.data_ptr(), n, _st(conv)), 'hg_demod_noise_lrelu_bwd')
         return gconv, gd, None, gw.sum(0).reshape(-1, 1), gb.sum(0)
 
 

@@ -29,7 +29,12 @@ int hg_modulate_fwd(const float *x, const float *s, float *out, int32_t B, int32
                     int32_t upsample, void *stream);
 /* gx = up^T(gout * (s+1));  gs[b,c] = sum(gout * up(x))  (gs may be NULL when s is NULL). */
 int hg_modulate_bwd(const float *gout, const float *x, const float *s, float *gx, float *gs, int32_t B,
-                    int32_t C, int32_t H, int32_t W, int32_t upsample, void *stream);
+                    int32_t C, int32_t H, int32_t W, int32_t upsample, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/* Scratch (partial sums, combined in fixed order: deterministic) for hg_modulate_bwd / hg_demod_noise_lrelu_bwd /
+ * hg_channel_sum on a (B, C, H, W) tensor. */
+size_t hg_nets_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
 
 /* out[b,o,i,j] = lrelu_0.2( conv[b,o,i,j] * d[b,o] + wn[o] * nzt[b,i,j] + bn[o] )
  * conv/out: (B,O,H,H);  d: (B,O) or NULL (no demodulation);  wn, bn: (O) = to_noise Linear(1,O);
@@ -42,7 +47,12 @@ int hg_demod_noise_lrelu_fwd(const float *conv, const float *d, const float *nzt
  * gwn_part[b,o] = sum m * nzt[b,i,j];  gbn_part[b,o] = sum m   (caller sums the parts over b). */
 int hg_demod_noise_lrelu_bwd(const float *gout, const float *out, const float *conv, const float *d,
                              const float *nzt, float *gconv, float *gd, float *gwn_part, float *gbn_part,
-                             int32_t B, int32_t O, int32_t H, int32_t S, void *stream);
+                             int32_t B, int32_t O, int32_t H, int32_t S, void *workspace, size_t workspace_bytes,
+                             void *stream);
+
+/* out[c] = sum_{b,p} g[b,c,p]: the bias gradient of a convolution (nn.Conv2d bias, histoGAN/histoGAN.py:510-518). */
+int hg_channel_sum(const float *g, float *out, int32_t B, int32_t C, int32_t HW, void *workspace,
+                   size_t workspace_bytes, void *stream);
 
 /* Fused multi-tensor DiffGrad step over one flat parameter buffer of n floats:
  *   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  dfc = 1/(1+exp(-|g_prev-g|));  g_prev = g

@@ -294,3 +294,14 @@ def test_train_step_matches_oracle(gpu_device, tmp_path):
             dn = (new[f'{p}.{k}'] - sd0[f'{p}.{k}']).numpy()
             do = (v.detach() - sd0[f'{p}.{k}']).numpy()
             assert np.max(np.abs(dn - do)[mask]) <= 0.02 * LR, (p, k)
+
+
+@pytest.mark.parametrize('shape', [(3, 5, 4, 4), (2, 16, 64, 64), (7, 3, 5, 9), (1, 1, 1, 1), (4, 130, 8, 8)])
+def test_channel_sum_matches_torch(shape, gpu_device):
+    from histogan_amd import ops
+    torch.manual_seed(5)
+    g = torch.randn(*shape, device=gpu_device)
+    ref = g.double().sum(dim=(0, 2, 3))
+    out = ops.channel_sum(g)
+    assert relmax(out.cpu().numpy(), ref.cpu().numpy()) <= 1e-6
+    assert torch.equal(out, ops.channel_sum(g))     # deterministic
