@@ -373,32 +373,30 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
     }
   };
 
-  bool have = false;
-  for (int chunk = (int)blockIdx.y - a.splits; chunk < a.nchunks; chunk += a.splits) {
-    if (have) {
-      __syncthreads();
+  // Double-buffered LDS (when two buffers fit in 160 KB), ONE barrier per chunk: while chunk c is multiplied out of
+  // buffer (it&1), the registers holding chunk c+1 are stored into the other buffer and re-filled with chunk c+2.
+  constexpr int BUFSZ = NBW * GP + KBW * G::CHS;   // floats of one (gout + halo) buffer
+  // (measured: +3..5 % for the 4-wave tiles; the pixel-split tiles (WS > 1) are faster single-buffered)
+  constexpr int NBUF = (WS == 1 && 2 * BUFSZ * 4 <= 160 * 1024) ? 2 : 1;
+  auto store = [&](int buf) __attribute__((always_inline)) {
+    float *G2 = smem + buf * BUFSZ, *X2 = G2 + NBW * GP;
 #pragma unroll
-      for (int i = 0; i < NGI; ++i)
-        if (NGI * GCPI == NBW || gcs + i * GCPI < NBW) {
-          float v = (gmask >> i) & 1u ? gr[i] : 0.f;
-          if (a.gscale != nullptr && ((gmask >> i) & 1u)) v *= a.gscale[(pb0 + gpi) * N + n0 + gcs + i * GCPI];
-          Gs[(gcs + i * GCPI) * GP + gp] = v;
-        }
+    for (int i = 0; i < NGI; ++i)
+      if (NGI * GCPI == NBW || gcs + i * GCPI < NBW) {
+        float v = (gmask >> i) & 1u ? gr[i] : 0.f;
+        if (a.gscale != nullptr && ((gmask >> i) & 1u)) v *= a.gscale[(pb0 + gpi) * N + n0 + gcs + i * GCPI];
+        G2[(gcs + i * GCPI) * GP + gp] = v;
+      }
 #pragma unroll
-      for (int i = 0; i < NHI; ++i)
-        if (hlane && (NHI * HCPI == KBW || hcs + i * HCPI < KBW)) {
-          float v = (hmask >> i) & 1ull ? hr[i] : 0.f;
-          if (a.iscale != nullptr && ((hmask >> i) & 1ull)) v *= a.iscale[(pb0 + himg) * K + k0 + hcs + i * HCPI];
-          Xs[(hcs + i * HCPI) * G::CHS + hrr] = v;
-        }
-      __syncthreads();
-    }
-    if (chunk + a.splits < a.nchunks) prefetch(chunk + a.splits);
-    if (!have) {
-      have = true;
-      continue;
-    }
-
+    for (int i = 0; i < NHI; ++i)
+      if (hlane && (NHI * HCPI == KBW || hcs + i * HCPI < KBW)) {
+        float v = (hmask >> i) & 1ull ? hr[i] : 0.f;
+        if (a.iscale != nullptr && ((hmask >> i) & 1ull)) v *= a.iscale[(pb0 + himg) * K + k0 + hcs + i * HCPI];
+        X2[(hcs + i * HCPI) * G::CHS + hrr] = v;
+      }
+  };
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const float *Gc = Ga + buf * BUFSZ, *Xc = Xa + buf * BUFSZ;
 #pragma unroll
     for (int q = 0; q < PC / 2 / WS; ++q) {
       // this wave's pixel pair: compile-time when WS == 1, else one of WS runtime alternatives
@@ -406,14 +404,42 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
       float bv[TAPS];
       auto rd = [&](int p0) __attribute__((always_inline)) {
         const int hoff = (p0 / (G::TW * G::TH)) * G::IMS + ((p0 / G::TW) % G::TH) * IS * G::TWp + (p0 % G::TW) * IS;
-        av = Ga[p0];
+        av = Gc[p0];
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) bv[t] = Xa[hoff + (PAD ? (t / 3) * G::TWp + (t % 3) : 0)];
+        for (int t = 0; t < TAPS; ++t) bv[t] = Xc[hoff + (PAD ? (t / 3) * G::TWp + (t % 3) : 0)];
       };
       if constexpr (WS == 1) rd(q * 2);
       else rd((q * WS + ws) * 2);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+    }
+  };
+
+  const int c0 = blockIdx.y, cs = a.splits;
+  if constexpr (NBUF == 2) {
+    if (c0 < a.nchunks) {
+      prefetch(c0);
+      store(0);
+      if (c0 + cs < a.nchunks) prefetch(c0 + cs);
+    }
+    __syncthreads();
+    int it = 0;
+    for (int chunk = c0; chunk < a.nchunks; chunk += cs, ++it) {
+      if (chunk + cs < a.nchunks) {
+        store((it & 1) ^ 1);
+        if (chunk + 2 * cs < a.nchunks) prefetch(chunk + 2 * cs);
+      }
+      compute(it & 1);
+      __syncthreads();
+    }
+  } else {
+    if (c0 < a.nchunks) prefetch(c0);
+    for (int chunk = c0; chunk < a.nchunks; chunk += cs) {
+      __syncthreads();
+      store(0);
+      __syncthreads();
+      if (chunk + cs < a.nchunks) prefetch(chunk + cs);
+      compute(0);
     }
   }
 
@@ -680,7 +706,8 @@ template <int WN, int WK, int WS, int TAPS, int LTW, int IS>
 int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
   constexpr int PC = IS == 2 ? 32 : 64;
   using G = CGeom<PC, LTW, TAPS == 9 ? 1 : 0, IS>;
-  const size_t lds = ((size_t)WN * 32 * (PC + 1) + (size_t)WK * 32 * G::CHS) * sizeof(float);
+  size_t lds = ((size_t)WN * 32 * (PC + 1) + (size_t)WK * 32 * G::CHS) * sizeof(float);
+  if (WS == 1 && 2 * lds <= 160 * 1024) lds *= 2;   // double buffered (NBUF in k_wgrad)
   auto kern = k_wgrad<WN, WK, WS, TAPS, PC, LTW, IS>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
