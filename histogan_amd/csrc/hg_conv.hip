@@ -65,11 +65,32 @@ __device__ __forceinline__ int fdiv(int e, float inv) {  // floor(e / d) for 0 <
 
 // ------------------------------------------------------------------------------------------------
 // output / data-gradient kernel
-template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM>
+// MT = MFMA tile: 32 (v_mfma_f32_32x32x2_f32, 2 channels per instruction) or 16 (v_mfma_f32_16x16x4_f32, 4 channels
+// per instruction, same flop rate) -- the 16-wide tile serves layers with <= 16 output channels (the first
+// discriminator block, the to-RGB convolutions) without multiplying 16 empty rows.
+template <int MT>
+struct MfmaTile {
+  typedef f32x16 acc_t;
+  static constexpr int NR = 16, KS = 2;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
+};
+template <>
+struct MfmaTile<16> {
+  typedef f32x4 acc_t;
+  static constexpr int NR = 4, KS = 4;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int r, int lk) { return 4 * lk + r; }
+};
+
+template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM, int MT>
 __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvArgs a) {
+  typedef MfmaTile<MT> M;
+  constexpr int KS = M::KS;         // channels per MFMA
+  static_assert(KC % KS == 0, "chunk must hold whole MFMA k-steps");
   constexpr int NT = WC * WP * 64;
-  constexpr int NB = WC * TC * 32;  // channels per block
-  constexpr int MB = WP * TP * 32;  // pixels per block
+  constexpr int NB = WC * TC * MT;  // channels per block
+  constexpr int MB = WP * TP * MT;  // pixels per block
   constexpr int WPT = KC * NB / 4;  // float4 per tap of a weight chunk
   constexpr int WTOT = TAPS * WPT;
   constexpr int NW = (WTOT + NT - 1) / NT;
@@ -86,6 +107,7 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
 
   const Geom &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane % MT, lk = lane / MT;   // position inside the MFMA tile / k index of the operand
   const int wc = wave % WC, wp = wave / WC;
   const int Hi = a.Hi, Wi = a.Wi, K = a.K, N = a.N;
 
@@ -129,19 +151,19 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
   int pixoff[TP];
 #pragma unroll
   for (int tp = 0; tp < TP; ++tp) {
-    const int p = (wp * TP + tp) * 32 + (lane & 31);
+    const int p = (wp * TP + tp) * MT + lm;
     const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
-    pixoff[tp] = pi * g.IMS + py * IS * g.TWp + px * IS + (lane >> 5) * g.CHS;
+    pixoff[tp] = pi * g.IMS + py * IS * g.TWp + px * IS + lk * g.CHS;
   }
-  const int aoff = (lane >> 5) * NB + wc * TC * 32 + (lane & 31);
+  const int aoff = lk * NB + wc * TC * MT + lm;
 
-  f32x16 acc[TC][TP];
+  typename M::acc_t acc[TC][TP];
 #pragma unroll
   for (int i = 0; i < TC; ++i)
 #pragma unroll
     for (int j = 0; j < TP; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < M::NR; ++r) acc[i][j][r] = 0.f;
 
   float xr[NH];
   f32x4 wr[NW];
@@ -201,26 +223,26 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
     for (int t = 0; t < TAPS; ++t) {
       const int toff = a.toff[t];
 #pragma unroll
-      for (int kk = 0; kk < KC / 2; ++kk) {
+      for (int kk = 0; kk < KC / KS; ++kk) {
         float av[TC], bv[TP];
 #pragma unroll
-        for (int i = 0; i < TC; ++i) av[i] = Ws[(t * KC + kk * 2) * NB + aoff + i * 32];
+        for (int i = 0; i < TC; ++i) av[i] = Ws[(t * KC + kk * KS) * NB + aoff + i * MT];
 #pragma unroll
-        for (int j = 0; j < TP; ++j) bv[j] = Xs[pixoff[j] + toff + kk * 2 * g.CHS];
+        for (int j = 0; j < TP; ++j) bv[j] = Xs[pixoff[j] + toff + kk * KS * g.CHS];
 #pragma unroll
         for (int i = 0; i < TC; ++i)
 #pragma unroll
-          for (int j = 0; j < TP; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TP; ++j) acc[i][j] = M::mma(av[i], bv[j], acc[i][j]);
       }
     }
   }
 
-  // ---- epilogue: D[i = channel][j = pixel]; row(i) = (r&3) + 8*(r>>2) + 4*(lane>>5), col(j) = lane&31
+  // ---- epilogue: D[i = channel][j = pixel]; 32x32: row(i) = (r&3) + 8*(r>>2) + 4*(lane>>5), col(j) = lane&31;
+  //      16x16: row = 4*(lane>>4) + r, col = lane&15
   const int HWo = a.Ho * a.Wo;
 #pragma unroll
   for (int j = 0; j < TP; ++j) {
-    const int p = (wp * TP + j) * 32 + (lane & 31);
+    const int p = (wp * TP + j) * MT + lm;
     const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
     const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
     if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
@@ -229,8 +251,8 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
 #pragma unroll
     for (int i = 0; i < TC; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = n0 + (wc * TC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      for (int r = 0; r < M::NR; ++r) {
+        const int ch = n0 + (wc * TC + i) * MT + M::row(r, lk);
         if (ch < N) {
           float v = acc[i][j][r];
           if (a.ksplit == 1) {   // split-K partials are scaled / biased by k_splitk_reduce
@@ -283,11 +305,13 @@ struct CGeom {
 // waves of a tile split the pixel pairs of each chunk between them and write separate slabs.  The next
 // chunk is fetched into registers while the MFMAs of the current one run (the kernel is allowed the full
 // 512-register budget: accumulators in AGPRs, staging in VGPRs).
-template <int WN, int WK, int WS, int TAPS, int PC, int LTW, int IS>
+template <int WN, int WK, int WS, int TAPS, int PC, int LTW, int IS, int MT>
 __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
+  typedef MfmaTile<MT> M;
+  constexpr int KS = M::KS;     // pixels per MFMA
   constexpr int NT = WN * WK * WS * 64;
-  constexpr int NBW = WN * 32;  // out channels (gout) per block
-  constexpr int KBW = WK * 32;  // in channels per block
+  constexpr int NBW = WN * MT;  // out channels (gout) per block
+  constexpr int KBW = WK * MT;  // in channels per block
   constexpr int PAD = TAPS == 9 ? 1 : 0;
   using G = CGeom<PC, LTW, PAD, IS>;
   constexpr int GP = PC + 1;  // odd pitch
@@ -297,19 +321,21 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
   float *Xs = smem + NBW * GP;  // [KBW][CHS]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane % MT, lk = lane / MT;
+  static_assert((1 << LTW) >= KS, "the pixels of one MFMA k-step must lie in one tile row");
   const int wn = wave % WN, wk = (wave / WN) % WK, ws = wave / (WN * WK);
   const int Hi = a.Hi, Wi = a.Wi, Ho = a.Ho, Wo = a.Wo, K = a.K, N = a.N;
   const int HWi = Hi * Wi, HWo = Ho * Wo;
   const int k0 = (blockIdx.x % a.ktiles) * KBW, n0 = (blockIdx.x / a.ktiles) * NBW;
 
-  f32x16 acc[TAPS];
+  typename M::acc_t acc[TAPS];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int r = 0; r < M::NR; ++r) acc[t][r] = 0.f;
 
-  const float *Ga = Gs + (wn * 32 + (lane & 31)) * GP + (lane >> 5);
-  const float *Xa = Xs + (wk * 32 + (lane & 31)) * G::CHS + (lane >> 5) * IS;
+  const float *Ga = Gs + (wn * MT + lm) * GP + lk;
+  const float *Xa = Xs + (wk * MT + lm) * G::CHS + lk * IS;
 
   // Staging maps: a pass moves CPI whole channels; thread -> (channel slot cs, position r) is fixed, so the
   // per-chunk address work is ONE offset per thread and each element costs one load + one LDS store.
@@ -398,8 +424,8 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
   auto compute = [&](int buf) __attribute__((always_inline)) {
     const float *Gc = Ga + buf * BUFSZ, *Xc = Xa + buf * BUFSZ;
 #pragma unroll
-    for (int q = 0; q < PC / 2 / WS; ++q) {
-      // this wave's pixel pair: compile-time when WS == 1, else one of WS runtime alternatives
+    for (int q = 0; q < PC / KS / WS; ++q) {
+      // this wave's pixel group (KS pixels of one row): compile-time when WS == 1, else one of WS alternatives
       float av;
       float bv[TAPS];
       auto rd = [&](int p0) __attribute__((always_inline)) {
@@ -408,10 +434,10 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) bv[t] = Xc[hoff + (PAD ? (t / 3) * G::TWp + (t % 3) : 0)];
       };
-      if constexpr (WS == 1) rd(q * 2);
-      else rd((q * WS + ws) * 2);
+      if constexpr (WS == 1) rd(q * KS);
+      else rd((q * WS + ws) * KS);
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
+      for (int t = 0; t < TAPS; ++t) acc[t] = M::mma(av, bv[t], acc[t]);
     }
   };
 
@@ -447,9 +473,9 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int k = k0 + wk * 32 + (lane & 31);
+      for (int r = 0; r < M::NR; ++r) {
+        const int n = n0 + wn * MT + M::row(r, lk);
+        const int k = k0 + wk * MT + lm;
         if (n < N && k < K) a.gw[((size_t)n * K + k) * TAPS + t] = acc[t][r];
       }
     return;
@@ -459,9 +485,9 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      const int k = k0 + wk * 32 + (lane & 31);
+    for (int r = 0; r < M::NR; ++r) {
+      const int n = n0 + wn * MT + M::row(r, lk);
+      const int k = k0 + wk * MT + lm;
       sb[((size_t)t * a.Np32 + n) * a.Kp32 + k] = acc[t][r];
     }
 }
@@ -475,7 +501,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
   const int kx = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int k = blockIdx.x * 32 + kx, t = blockIdx.y, n = blockIdx.z;
   const size_t sstride = (size_t)TAPS * Np32 * Kp32;
-  const float *p = slab + ((size_t)t * Np32 + n) * Kp32 + k;   // k < Kp32 always (Kp32 is a multiple of 32)
+  const float *p = slab + ((size_t)t * Np32 + n) * Kp32 + (k < Kp32 ? k : 0);   // Kp32: multiple of the tile (16 / 32)
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int sp = grp;
   for (; sp + 24 < splits; sp += 32) {
@@ -565,7 +591,7 @@ struct Taps {
 };
 
 // tile shape + K split of one k_conv launch
-enum ConvTile { TILE_32x256, TILE_64x256, TILE_128x128, TILE_64x64 };
+enum ConvTile { TILE_16x256, TILE_32x256, TILE_64x256, TILE_128x128, TILE_64x64 };
 struct ConvPlan {
   ConvTile tile;
   int ksplit;
@@ -580,6 +606,7 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
   const bool wide256 = Wc > 8 && Hc > 8, wide128 = Wc > 4 && Hc > 4;
   ConvPlan p;
   p.ksplit = 1;
+  if (N <= 16 && wide256) { p.tile = TILE_16x256; return p; }
   if (N <= 32 && wide256) { p.tile = TILE_32x256; return p; }
   if (N <= 64 && wide256 && blocks(64, 256) >= 384) { p.tile = TILE_64x256; return p; }
   if (N > 64 && wide128 && blocks(128, 128) >= 384) { p.tile = TILE_128x128; return p; }
@@ -602,9 +629,9 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
 
 inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st);
 
-template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM = false>
+template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM = false, int MT = 32>
 int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t st) {
-  constexpr int NB = WC * TC * 32, MB = WP * TP * 32, NT = WC * WP * 64;
+  constexpr int NB = WC * TC * MT, MB = WP * TP * MT, NT = WC * WP * 64;
   int lo_y = 0, hi_y = 0, lo_x = 0, hi_x = 0;
   for (int t = 0; t < TAPS; ++t) {
     lo_y = tp.dy[t] < lo_y ? tp.dy[t] : lo_y; hi_y = tp.dy[t] > hi_y ? tp.dy[t] : hi_y;
@@ -619,7 +646,7 @@ int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t
   a.wrow_dy = TAPS > tp.ntx ? (tp.w[tp.ntx] - tp.w[0]) * a.Kp : 0;
   a.ksplit = ksplit;
   const size_t lds = ((size_t)TAPS * KC * NB + (size_t)KC * a.g.CHS) * sizeof(float);
-  auto kern = k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM>;
+  auto kern = k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -654,6 +681,8 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
   ConvPlan p = plan_conv(a.B, a.K, a.N, a.Hc, a.Wc, IS, a.os, ws != nullptr);
   if (conv_ws_bytes(p, a.B, a.N, a.Ho, a.Wo) > ws_bytes) p.ksplit = 1;   // too little scratch: no K split
   switch (p.tile) {
+    case TILE_16x256:   // 16 ch x 256 px on the 16x16x4 MFMA
+      return launch_conv<1, 4, 1, 4, TAPS, 4, IS, false, 16>(a, tp, 1, true, st);
     case TILE_32x256: return launch_conv<1, 4, 1, 2, TAPS, KC, IS>(a, tp, 1, true, st);
     case TILE_64x256: return launch_conv<1, 4, 2, 2, TAPS, KC, IS>(a, tp, 1, true, st);
     case TILE_128x128: return launch_conv<2, 2, 2, 2, TAPS, KC, IS>(a, tp, 1, true, st);
@@ -663,6 +692,7 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
 
 struct WgradPlan {
   int PC, lTW, tiles_x, tiles_y, groups;
+  int MT;          // MFMA tile: 16 when both channel counts are <= 16, else 32
   int WN, WK, WS;  // waves per block along n / k / pixel split
   int nchunks, splits, ktiles, ntiles, Kp32, Np32;
   size_t slab_bytes;
@@ -673,42 +703,48 @@ inline int out_size(int in, int stride) { return (in - 1) / stride + 1; }  // k 
 WgradPlan make_wgrad_plan(int B, int K, int N, int Hi, int Wi, int ksize, int stride) {
   WgradPlan p;
   const int Ho = out_size(Hi, stride), Wo = out_size(Wi, stride);
-  p.PC = stride == 2 ? 32 : 64;
+  p.MT = (N <= 16 && K <= 16) ? 16 : 32;
   int lTW = ceil_log2(Wo < 2 ? 2 : Wo);
+  if (p.MT == 16 && lTW < 2) lTW = 2;   // 4 pixels per 16x16x4 MFMA must share a row
   if (lTW > 5) lTW = 5;
   p.lTW = lTW;
+  // pixels per chunk: the 16x16 tile does 4x less MFMA work per pixel, so it takes 128-pixel chunks where the halo of
+  // 128 pixels still fits one staging pass (rows >= 8 wide)
+  p.PC = stride == 2 ? 32 : ((p.MT == 16 && lTW >= 3) ? 128 : 64);
   const int TW = 1 << lTW, TH = (p.PC / TW) < TW ? (p.PC / TW) : TW, NI = p.PC / (TW * TH);
   p.tiles_x = (Wo + TW - 1) / TW;
   p.tiles_y = (Ho + TH - 1) / TH;
   p.groups = (B + NI - 1) / NI;
   p.nchunks = p.tiles_x * p.tiles_y * p.groups;
-  if (stride == 2) {  // only two shapes are instantiated for stride 2
+  if (p.MT == 16) {
+    p.WN = p.WK = 1;
+  } else if (stride == 2) {  // only two shapes are instantiated for stride 2
     p.WN = p.WK = (N > 32 && K > 32) ? 2 : 1;
   } else {
     p.WN = N > 32 ? 2 : 1;
     p.WK = K > 32 ? 2 : 1;
   }
   p.WS = 4 / (p.WN * p.WK);
-  p.ktiles = (K + p.WK * 32 - 1) / (p.WK * 32);
-  p.ntiles = (N + p.WN * 32 - 1) / (p.WN * 32);
+  p.ktiles = (K + p.WK * p.MT - 1) / (p.WK * p.MT);
+  p.ntiles = (N + p.WN * p.MT - 1) / (p.WN * p.MT);
   const int tiles = p.ktiles * p.ntiles;
   int s = (512 + tiles - 1) / tiles;
   if (s > p.nchunks) s = p.nchunks;
   if (s < 1) s = 1;
   p.splits = s;
-  p.Kp32 = p.ktiles * p.WK * 32;
-  p.Np32 = p.ntiles * p.WN * 32;
+  p.Kp32 = p.ktiles * p.WK * p.MT;
+  p.Np32 = p.ntiles * p.WN * p.MT;
   p.slab_bytes = (size_t)s * p.WS * ksize * ksize * p.Kp32 * p.Np32 * sizeof(float);
   return p;
 }
 
-template <int WN, int WK, int WS, int TAPS, int LTW, int IS>
+template <int WN, int WK, int WS, int TAPS, int LTW, int IS, int MT = 32>
 int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
-  constexpr int PC = IS == 2 ? 32 : 64;
+  constexpr int PC = IS == 2 ? 32 : ((MT == 16 && LTW >= 3) ? 128 : 64);
   using G = CGeom<PC, LTW, TAPS == 9 ? 1 : 0, IS>;
-  size_t lds = ((size_t)WN * 32 * (PC + 1) + (size_t)WK * 32 * G::CHS) * sizeof(float);
+  size_t lds = ((size_t)WN * MT * (PC + 1) + (size_t)WK * MT * G::CHS) * sizeof(float);
   if (WS == 1 && 2 * lds <= 160 * 1024) lds *= 2;   // double buffered (NBUF in k_wgrad)
-  auto kern = k_wgrad<WN, WK, WS, TAPS, PC, LTW, IS>;
+  auto kern = k_wgrad<WN, WK, WS, TAPS, PC, LTW, IS, MT>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -720,6 +756,9 @@ int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
 
 template <int TAPS, int LTW, int IS>
 int launch_wgrad_g(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
+  if constexpr (LTW >= 2) {
+    if (p.MT == 16) return launch_wgrad_k<1, 1, 4, TAPS, LTW, IS, 16>(a, p, st);
+  }
   if (p.WN == 2 && p.WK == 2) return launch_wgrad_k<2, 2, 1, TAPS, LTW, IS>(a, p, st);
   if constexpr (IS == 1) {
     if (p.WN == 2) return launch_wgrad_k<2, 1, 2, TAPS, LTW, IS>(a, p, st);

@@ -15,11 +15,14 @@ CASES = [
     (2, 8, 3, 32, 32, 1), (4, 130, 70, 16, 16, 3), (2, 32, 32, 2, 2, 3), (1, 1, 1, 1, 1, 3),
     (3, 40, 200, 4, 4, 3), (2, 24, 64, 128, 128, 3), (2, 64, 3, 64, 64, 1), (5, 17, 19, 8, 8, 1),
     (2, 3, 16, 32, 32, 1), (8, 96, 160, 8, 8, 3), (1, 20, 48, 16, 40, 3), (33, 9, 6, 4, 4, 3),
+    # <= 16 output channels on wide maps: the 16x16x4 MFMA tile (first discriminator block, to-RGB)
+    (2, 3, 16, 64, 64, 3), (2, 16, 16, 64, 64, 3), (3, 16, 3, 32, 32, 3), (2, 40, 3, 32, 32, 1), (1, 16, 16, 20, 44, 3),
+    (2, 7, 12, 16, 16, 3), (2, 16, 16, 8, 8, 3),
 ]
 
 
 # stride-2 cases (3x3): the discriminator's down-sampling convolution (histoGAN/histoGAN.py:517-518)
-CASES_S2 = [(2, 16, 16, 32, 32), (3, 5, 7, 9, 13), (2, 64, 64, 16, 16), (4, 70, 130, 8, 8), (2, 32, 32, 64, 64),
+CASES_S2 = [(2, 16, 16, 64, 64), (2, 16, 16, 32, 32), (3, 5, 7, 9, 13), (2, 64, 64, 16, 16), (4, 70, 130, 8, 8), (2, 32, 32, 64, 64),
             (1, 3, 4, 5, 4), (8, 128, 128, 4, 4), (2, 16, 16, 128, 128), (5, 33, 65, 2, 2), (1, 2, 2, 1, 1)]
 
 
