@@ -56,6 +56,10 @@ struct ConvArgs {
   int ntx, wrow0, wrow_dy, wrow_dx;  // packed-weight row of tap t = wrow0 + (t / ntx)*wrow_dy + (t % ntx)*wrow_dx
   int ksplit;      // > 1: blockIdx.z handles a K range and writes raw partial sums to slab[z] (out layout)
   float *slab;
+  // fused generator epilogue (hg_modconv2d_fwd): v = acc*oscale + bias[n] + noise_w[n]*noise_img[b][y][x]; lrelu
+  const float *noise_w, *noise_img;
+  int noise_S;     // noise_img is (B, noise_S, noise_S)
+  float slope;     // > 0: LeakyReLU slope applied last; 0: none
   Geom g;
 };
 
@@ -83,7 +87,9 @@ struct MfmaTile<16> {
   static __device__ __forceinline__ int row(int r, int lk) { return 4 * lk + r; }
 };
 
-template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM, int MT>
+// FE (fused extras) = input scale / output scale / noise / LeakyReLU support; the plain instantiation (bias only)
+// keeps ~90 fewer registers and is what the training hot path runs.
+template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM, int MT, bool FE>
 __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvArgs a) {
   typedef MfmaTile<MT> M;
   constexpr int KS = M::KS;         // channels per MFMA
@@ -166,6 +172,17 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
       for (int r = 0; r < M::NR; ++r) acc[i][j][r] = 0.f;
 
   float xr[NH];
+  float xs[FE ? NH : 1];     // modulation scale of each staged element (only live when iscale is given)
+  int soff[FE ? NH : 1];     // (b*K + kc) of each staged element
+  if (FE && a.iscale != nullptr) {
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      const int e0 = tid + i * NT, e = e0 < htot ? e0 : 0;
+      const int kc = fdiv(e, g.inv_HALO);
+      const int bb = b0 + fdiv(e - kc * g.HALO, g.inv_IMS);
+      soff[i] = (bb < a.B ? bb : a.B - 1) * K + kc;
+    }
+  }
   f32x4 wr[NW];
   const int nchunks_all = (K + KC - 1) / KC;
   const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;   // chunks per K split
@@ -180,14 +197,13 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
     for (int i = 0; i < NH; ++i) {
       bool ok = goff[i] >= 0;
       if (krem < KC) ok = ok && fdiv(tid + i * NT, g.inv_HALO) < krem;   // last, partial chunk only
-      float v = ok ? inb[goff[i]] : 0.f;
-      if (a.iscale != nullptr && ok) {
-        const int e = tid + i * NT;
-        const int kc = fdiv(e, g.inv_HALO);
-        const int img = fdiv(e - kc * g.HALO, g.inv_IMS);
-        v *= a.iscale[(b0 + img) * K + c * KC + kc];
+      xr[i] = ok ? inb[goff[i]] : 0.f;
+      if constexpr (FE) {
+        if (a.iscale != nullptr) {   // unconditional (clamped) load; multiplied in at the LDS store
+          const int si = soff[i] + c * KC;
+          xs[i] = a.iscale[si < a.B * K ? si : a.B * K - 1];
+        }
       }
-      xr[i] = v;
     }
     const float *wb = a.wt + (size_t)c * KC * a.Np + n0;
 #pragma unroll
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
 #pragma unroll
       for (int i = 0; i < NH; ++i) {
         const int e = tid + i * NT;
-        if (e < htot) Xs[fdiv(e, g.inv_HALO) * (g.CHS - g.HALO) + e] = xr[i];
+        if (e < htot) Xs[fdiv(e, g.inv_HALO) * (g.CHS - g.HALO) + e] = (FE && a.iscale != nullptr) ? xr[i] * xs[FE ? i : 0] : xr[i];
       }
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
@@ -240,42 +256,94 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
   // ---- epilogue: D[i = channel][j = pixel]; 32x32: row(i) = (r&3) + 8*(r>>2) + 4*(lane>>5), col(j) = lane&31;
   //      16x16: row = 4*(lane>>4) + r, col = lane&15
   const int HWo = a.Ho * a.Wo;
+  const bool fin = a.ksplit == 1;   // split-K partials get their epilogue in k_splitk_reduce
+  if constexpr (!FE) {
 #pragma unroll
-  for (int j = 0; j < TP; ++j) {
-    const int p = (wp * TP + j) * MT + lm;
-    const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
-    const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
-    if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
-    const size_t pofs = ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
-    float *ob = (a.ksplit > 1 ? a.slab + (size_t)blockIdx.z * a.B * N * HWo : a.out) + pofs;
+    for (int j = 0; j < TP; ++j) {
+      const int p = (wp * TP + j) * MT + lm;
+      const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
+      const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
+      if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
+      const size_t pofs = ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
+      float *ob = (fin ? a.out : a.slab + (size_t)blockIdx.z * a.B * N * HWo) + pofs;
 #pragma unroll
-    for (int i = 0; i < TC; ++i) {
+      for (int i = 0; i < TC; ++i) {
+#pragma unroll
+        for (int r = 0; r < M::NR; ++r) {
+          const int ch = n0 + (wc * TC + i) * MT + M::row(r, lk);
+          if (ch < N) {
+            float v = acc[i][j][r];
+            if (fin && a.bias) v += a.bias[ch];
+            ob[(size_t)ch * HWo] = v;
+          }
+        }
+      }
+    }
+  } else {
+    // per-channel epilogue parameters first (before any store: the compiler cannot hoist them past possibly
+    // aliasing stores itself)
+    float pbias[TC][M::NR], pnw[TC][M::NR];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
 #pragma unroll
       for (int r = 0; r < M::NR; ++r) {
         const int ch = n0 + (wc * TC + i) * MT + M::row(r, lk);
-        if (ch < N) {
-          float v = acc[i][j][r];
-          if (a.ksplit == 1) {   // split-K partials are scaled / biased by k_splitk_reduce
-            if (a.oscale) v *= a.oscale[b * N + ch];
-            if (a.bias) v += a.bias[ch];
+        const int cc = ch < N ? ch : N - 1;
+        pbias[i][r] = (fin && a.bias) ? a.bias[cc] : 0.f;
+        pnw[i][r] = (fin && a.noise_img) ? a.noise_w[cc] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+      const int p = (wp * TP + j) * MT + lm;
+      const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
+      const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
+      if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
+      const size_t pofs = ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
+      float *ob = (fin ? a.out : a.slab + (size_t)blockIdx.z * a.B * N * HWo) + pofs;
+      const float nz = (a.noise_img != nullptr && fin)
+                           ? a.noise_img[((size_t)b * a.noise_S + cy * a.os + a.oy) * a.noise_S + cx * a.os + a.ox] : 0.f;
+      float posc[TC][M::NR];
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int r = 0; r < M::NR; ++r) {
+          const int ch = n0 + (wc * TC + i) * MT + M::row(r, lk);
+          posc[i][r] = (fin && a.oscale) ? a.oscale[b * N + (ch < N ? ch : N - 1)] : 1.f;
+        }
+#pragma unroll
+      for (int i = 0; i < TC; ++i) {
+#pragma unroll
+        for (int r = 0; r < M::NR; ++r) {
+          const int ch = n0 + (wc * TC + i) * MT + M::row(r, lk);
+          if (ch < N) {
+            float v = fmaf(acc[i][j][r], posc[i][r], fmaf(pnw[i][r], nz, pbias[i][r]));
+            if (fin && a.slope > 0.f) v = v > 0.f ? v : a.slope * v;
+            ob[(size_t)ch * HWo] = v;
           }
-          ob[(size_t)ch * HWo] = v;
         }
       }
     }
   }
 }
 
-// out[b][n][p] = oscale[b][n] * sum_z slab[z][b][n][p] + bias[n]   (fixed order: deterministic)
+// out[b][n][p] = epilogue( sum_z slab[z][b][n][p] )   (fixed order: deterministic); epilogue as in k_conv
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__ slab, float *__restrict__ out,
                                                        const float *__restrict__ oscale, const float *__restrict__ bias,
-                                                       long long total, int HWo, int N, int ksplit) {
+                                                       const float *__restrict__ noise_w, const float *__restrict__ noise_img,
+                                                       int noise_S, float slope, long long total, int HWo, int Wo, int N,
+                                                       int ksplit) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     float v = 0.f;
     for (int z = 0; z < ksplit; ++z) v += slab[(size_t)z * total + i];
     const long long bn = i / HWo;
-    if (oscale) v *= oscale[bn];
-    if (bias) v += bias[bn % N];
+    const int n = (int)(bn % N);
+    float add = bias ? bias[n] : 0.f;
+    if (noise_img) {
+      const int p = (int)(i - bn * HWo), y = p / Wo, x = p - y * Wo;
+      add = fmaf(noise_w[n], noise_img[((size_t)(bn / N) * noise_S + y) * noise_S + x], add);
+    }
+    v = oscale ? fmaf(v, oscale[bn], add) : v + add;
+    if (slope > 0.f) v = v > 0.f ? v : slope * v;
     out[i] = v;
   }
 }
@@ -417,7 +485,22 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
     for (int i = 0; i < NHI; ++i)
       if (hlane && (NHI * HCPI == KBW || hcs + i * HCPI < KBW)) {
         float v = (hmask >> i) & 1ull ? hr[i] : 0.f;
-        if (a.iscale != nullptr && ((hmask >> i) & 1ull)) v *= a.iscale[(pb0 + himg) * K + k0 + hcs + i * HCPI];
+        if (a.iscale != nullptr) {
+          if constexpr (G::NI == 1) {
+            // one image per chunk: the HCPI candidate scales of pass i are wave-uniform -> scalar loads + select
+            const float *sp = a.iscale + (size_t)pb0 * K + k0;
+            float sc = 1.f;
+#pragma unroll
+            for (int c = 0; c < HCPI; ++c) {
+              const int kk = i * HCPI + c;
+              const float sv = sp[k0 + kk < K ? kk : K - 1 - k0];
+              sc = hcs == c ? sv : sc;
+            }
+            v *= sc;
+          } else if ((hmask >> i) & 1ull) {
+            v *= a.iscale[(pb0 + himg) * K + k0 + hcs + i * HCPI];
+          }
+        }
         X2[(hcs + i * HCPI) * G::CHS + hrr] = v;
       }
   };
@@ -646,7 +729,8 @@ int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t
   a.wrow_dy = TAPS > tp.ntx ? (tp.w[tp.ntx] - tp.w[0]) * a.Kp : 0;
   a.ksplit = ksplit;
   const size_t lds = ((size_t)TAPS * KC * NB + (size_t)KC * a.g.CHS) * sizeof(float);
-  auto kern = k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT>;
+  const bool fe = a.iscale || a.oscale || a.noise_img || a.slope > 0.f;
+  auto kern = fe ? k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, true> : k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, false>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -666,8 +750,8 @@ inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st) {
   const long long total = (long long)a.B * a.N * a.Ho * a.Wo;
   long long nb = (total + 255) / 256;
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)nb), dim3(256), 0, st, a.slab, a.out, a.oscale, a.bias, total,
-                     a.Ho * a.Wo, a.N, ksplit);
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)nb), dim3(256), 0, st, a.slab, a.out, a.oscale, a.bias, a.noise_w,
+                     a.noise_img, a.noise_S, a.slope, total, a.Ho * a.Wo, a.Wo, a.N, ksplit);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
@@ -840,13 +924,17 @@ size_t hg_conv2d_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t Hi, in
   return conv_ws_bytes(plan_conv(B, K, N, Ho, Wo, stride, 1, true), B, N, Ho, Wo);
 }
 
-int hg_conv2d_fwd(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
-                  const float *bias, int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
-                  int32_t stride, void *workspace, size_t workspace_bytes, void *stream) {
+static int conv2d_fwd_impl(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
+                           const float *bias, const float *noise_w, const float *noise_img, int32_t noise_S,
+                           float lrelu_slope, int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
+                           int32_t stride, void *workspace, size_t workspace_bytes, void *stream) {
   if (!in || !wt || !out || !conv_args_ok(B, K, N, Hi, Wi, ksize, stride)) return HG_EINVAL;
+  if ((noise_img != nullptr) != (noise_w != nullptr) || lrelu_slope < 0.f) return HG_EINVAL;
+  if (noise_img && (noise_S < out_size(Hi, stride) || noise_S < out_size(Wi, stride))) return HG_EINVAL;
   if (!fits_i32(B, K, N, Hi, Wi)) return HG_EUNSUPPORTED;
   ConvArgs a;
   a.in = in; a.wt = wt; a.out = out; a.iscale = iscale; a.oscale = oscale; a.bias = bias;
+  a.noise_w = noise_w; a.noise_img = noise_img; a.noise_S = noise_S; a.slope = lrelu_slope;
   a.B = B; a.K = K; a.N = N; a.Hi = Hi; a.Wi = Wi;
   a.Ho = a.Hc = out_size(Hi, stride); a.Wo = a.Wc = out_size(Wi, stride);
   a.os = 1; a.oy = a.ox = 0;
@@ -863,6 +951,21 @@ int hg_conv2d_fwd(const float *in, const float *wt, float *out, const float *isc
                      : dispatch_conv<9, 2>(a, tp, workspace, workspace_bytes, st);
 }
 
+int hg_conv2d_fwd(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
+                  const float *bias, int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
+                  int32_t stride, void *workspace, size_t workspace_bytes, void *stream) {
+  return conv2d_fwd_impl(in, wt, out, iscale, oscale, bias, nullptr, nullptr, 0, 0.f, B, K, N, Hi, Wi, ksize, stride,
+                         workspace, workspace_bytes, stream);
+}
+
+int hg_modconv2d_fwd(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
+                     const float *bias, const float *noise_w, const float *noise_img, int32_t noise_S,
+                     float lrelu_slope, int32_t B, int32_t K, int32_t N, int32_t H, int32_t W, int32_t ksize,
+                     void *workspace, size_t workspace_bytes, void *stream) {
+  return conv2d_fwd_impl(in, wt, out, iscale, oscale, bias, noise_w, noise_img, noise_S, lrelu_slope, B, K, N, H, W, ksize,
+                         1, workspace, workspace_bytes, stream);
+}
+
 int hg_conv2d_dgrad(const float *gout, const float *wt, float *gin, const float *iscale, const float *oscale,
                     int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride,
                     void *workspace, size_t workspace_bytes, void *stream) {
@@ -871,6 +974,7 @@ int hg_conv2d_dgrad(const float *gout, const float *wt, float *gin, const float 
   hipStream_t st = (hipStream_t)stream;
   ConvArgs a;
   a.in = gout; a.wt = wt; a.out = gin; a.iscale = iscale; a.oscale = oscale; a.bias = nullptr;
+  a.noise_w = a.noise_img = nullptr; a.noise_S = 0; a.slope = 0.f;
   a.B = B; a.K = K; a.N = N;
   a.Hi = out_size(Hi, stride); a.Wi = out_size(Wi, stride);  // the kernel's input is grad_out
   a.Ho = Hi; a.Wo = Wi;

@@ -203,9 +203,13 @@ __global__ __launch_bounds__(256) void k_dnl_fwd(const float *__restrict__ conv,
 }
 
 // m = gout * lrelu'(out): gconv = m*d; partial sums of m*conv, m*nzt, m per (chunk, plane)
+// conv == NULL (fused forward: the pre-activation was never stored): conv*d is recovered from out,
+//   pre = out > 0 ? out : out / 0.2;  conv*d = pre - (wn*nzt + bn), and the first partial sum is sum m*conv*d
+//   (the caller divides by d).
 __global__ __launch_bounds__(256) void k_dnl_bwd(const float *__restrict__ gout, const float *__restrict__ out,
                                                  const float *__restrict__ conv, const float *__restrict__ d,
-                                                 const float *__restrict__ nzt, float *__restrict__ gconv,
+                                                 const float *__restrict__ nzt, const float *__restrict__ wn,
+                                                 const float *__restrict__ bn, float *__restrict__ gconv,
                                                  float *__restrict__ part /* [3][planes][chunks] */, int O, int H, int S) {
   __shared__ float sm[4];
   const int bo = blockIdx.y, b = bo / O;
@@ -213,14 +217,21 @@ __global__ __launch_bounds__(256) void k_dnl_bwd(const float *__restrict__ gout,
   const float dd = d ? d[bo] : 1.f;
   const size_t base = (size_t)bo * hw;
   const float *np = nzt + (size_t)b * S * S;
+  const float w_ = conv ? 0.f : wn[bo % O], b_ = conv ? 0.f : bn[bo % O];
   float a_d = 0.f, a_w = 0.f, a_b = 0.f;
   if ((H & 3) == 0 && (S & 3) == 0) {
     for (int e = blockIdx.x * 256 + threadIdx.x; e < hw / 4; e += gridDim.x * 256) {
       const int i = (e * 4) / H, j = e * 4 - i * H;
       const float4 g = reinterpret_cast<const float4 *>(gout + base)[e];
       const float4 o = reinterpret_cast<const float4 *>(out + base)[e];
-      const float4 c = reinterpret_cast<const float4 *>(conv + base)[e];
       const float4 n = *reinterpret_cast<const float4 *>(np + (size_t)i * S + j);
+      float4 c;
+      if (conv) {
+        c = reinterpret_cast<const float4 *>(conv + base)[e];
+      } else {
+        c.x = (o.x > 0.f ? o.x : 5.f * o.x) - fmaf(w_, n.x, b_); c.y = (o.y > 0.f ? o.y : 5.f * o.y) - fmaf(w_, n.y, b_);
+        c.z = (o.z > 0.f ? o.z : 5.f * o.z) - fmaf(w_, n.z, b_); c.w = (o.w > 0.f ? o.w : 5.f * o.w) - fmaf(w_, n.w, b_);
+      }
       float4 m;
       m.x = g.x * (o.x > 0.f ? 1.f : 0.2f); m.y = g.y * (o.y > 0.f ? 1.f : 0.2f);
       m.z = g.z * (o.z > 0.f ? 1.f : 0.2f); m.w = g.w * (o.w > 0.f ? 1.f : 0.2f);
@@ -233,11 +244,14 @@ __global__ __launch_bounds__(256) void k_dnl_bwd(const float *__restrict__ gout,
     }
   } else {
     for (int e = blockIdx.x * 256 + threadIdx.x; e < hw; e += gridDim.x * 256) {
-      const float m = gout[base + e] * (out[base + e] > 0.f ? 1.f : 0.2f);
+      const float o = out[base + e];
+      const float m = gout[base + e] * (o > 0.f ? 1.f : 0.2f);
       gconv[base + e] = m * dd;
       const int i = e / H, j = e - i * H;
-      a_d = fmaf(m, conv[base + e], a_d);
-      a_w = fmaf(m, np[(size_t)i * S + j], a_w);
+      const float nz = np[(size_t)i * S + j];
+      const float c = conv ? conv[base + e] : (o > 0.f ? o : 5.f * o) - fmaf(w_, nz, b_);
+      a_d = fmaf(m, c, a_d);
+      a_w = fmaf(m, nz, a_w);
       a_b += m;
     }
   }
@@ -390,17 +404,19 @@ int hg_demod_noise_lrelu_fwd(const float *conv, const float *d, const float *nzt
 }
 
 int hg_demod_noise_lrelu_bwd(const float *gout, const float *out, const float *conv, const float *d,
-                             const float *nzt, float *gconv, float *gd, float *gwn_part, float *gbn_part,
-                             int32_t B, int32_t O, int32_t H, int32_t S, void *workspace, size_t workspace_bytes,
-                             void *stream) {
-  if (!gout || !out || !conv || !nzt || !gconv || !gwn_part || !gbn_part || B <= 0 || O <= 0 || H <= 0 || S < H)
+                             const float *nzt, const float *wn, const float *bn, float *gconv, float *gd,
+                             float *gwn_part, float *gbn_part, int32_t B, int32_t O, int32_t H, int32_t S,
+                             void *workspace, size_t workspace_bytes, void *stream) {
+  if (!gout || !out || !nzt || !gconv || !gwn_part || !gbn_part || B <= 0 || O <= 0 || H <= 0 || S < H)
     return HG_EINVAL;
+  if (!conv && (!wn || !bn)) return HG_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int planes = B * O;
   const int chunks = plane_chunks(planes, (long long)H * H / 4);
   if (!workspace || workspace_bytes < (size_t)3 * planes * chunks * sizeof(float)) return HG_EWORKSPACE;
   float *part = (float *)workspace;
-  hipLaunchKernelGGL(k_dnl_bwd, dim3(chunks, planes), dim3(256), 0, st, gout, out, conv, d, nzt, gconv, part, O, H, S);
+  hipLaunchKernelGGL(k_dnl_bwd, dim3(chunks, planes), dim3(256), 0, st, gout, out, conv, d, nzt, wn, bn, gconv, part, O, H,
+                     S);
   HG_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_dnl_bwd_finish, dim3((planes + 255) / 256), dim3(256), 0, st, part, gd, gwn_part, gbn_part, planes,
                      chunks);

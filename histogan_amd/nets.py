@@ -95,7 +95,10 @@ class RGBBlock(nn.Module):
         return self.forward_(x, prev_rgb, self.to_style(istyle))
 
     def forward_(self, x, prev_rgb, style):
-        x = self.conv(x, style)
+        if GeneratorBlock.FUSED and x.is_cuda and not self.conv.demod and self.conv.kernel == 1:
+            x = ops.modconv_stage(x, style, self.conv.weight, demod=False, upsample=False, act=False)
+        else:
+            x = self.conv(x, style)
         if prev_rgb is not None:
             x = x + prev_rgb
         if self.upsample is not None:
@@ -116,7 +119,17 @@ class GeneratorBlock(nn.Module):
         self.activation = leaky_relu()
         self.to_rgb = RGBBlock(latent_dim, filters, upsample_rgb, rgba)
 
+    # Execution plan of one convolution stage.  FUSED = True runs modulation + convolution + demodulation + noise +
+    # LeakyReLU as ONE forward launch (ops.modconv_stage -> hg_modconv2d_fwd).  Measured on MI355X at the C3 shapes
+    # (tools/modconv_probe.py) the fused forward saves 0.03-0.17 ms per stage but its backward needs the modulation
+    # inside the weight-gradient kernel (+0.06-0.1 ms), so the train step is 1-3 % faster with the three-kernel
+    # plan below (prologue kernel, convolution, epilogue kernel); inference-only use profits from FUSED.
+    FUSED = False
+
     def _stage(self, conv, x, style, nzt, to_noise, upsample):
+        if self.FUSED and conv.stride == 1 and conv.dilation == 1 and conv.kernel in (1, 3):
+            return ops.modconv_stage(x, style, conv.weight, nzt, to_noise.weight, to_noise.bias,
+                                     demod=conv.demod, upsample=upsample, act=True)
         c = conv.contract(x, style, upsample)
         d = conv.demod_coeff(style) if conv.demod else None
         return ops.demod_noise_lrelu(c, d, nzt, to_noise.weight, to_noise.bias)

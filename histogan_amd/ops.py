@@ -115,7 +115,8 @@ class _DemodNoiseLrelu(torch.autograd.Function):
             gb = torch.empty((B, O), dtype=torch.float32, device=conv.device)
             ws, n = _ws(conv, B, O, H, H)
             check(lib.hg_demod_noise_lrelu_bwd(g.data_ptr(), out.data_ptr(), conv.data_ptr(),
-                                               None if d is None else d.data_ptr(), nzt.data_ptr(), gconv.data_ptr(),
+                                               None if d is None else d.data_ptr(), nzt.data_ptr(), None, None,
+                                               gconv.data_ptr(),
                                                None if gd is None else gd.data_ptr(), gw.data_ptr(), gb.data_ptr(),
                                                B, O, H, S, ws.data_ptr(), n, _st(conv)), 'hg_demod_noise_lrelu_bwd')
         return gconv, gd, None, gw.sum(0).reshape(-1, 1), gb.sum(0)
@@ -124,3 +125,108 @@ class _DemodNoiseLrelu(torch.autograd.Function):
 def demod_noise_lrelu(conv, d, nzt, wn, bn):
     """lrelu_0.2(conv * d[:, :, None, None] + wn[o] * nzt[b, i, j] + bn[o]);  wn: Linear(1,O).weight (O,1)."""
     return _DemodNoiseLrelu.apply(conv, d, nzt, wn, bn)
+
+
+class _ModConvStage(torch.autograd.Function):
+    """One generator convolution stage as a single forward launch (hg_modconv2d_fwd):
+
+        out = act( d[b,o] * conv(up?(x) * (style+1), W) + wn[o] * nzt[b,i,j] + bn[o] ),   d = demodulation
+
+    == Conv2DMod.forward + noise add + LeakyReLU(0.2) of GeneratorBlock.forward (histoGAN/histoGAN.py:420-440,
+    465-476); with act=False / no noise it is the to-RGB convolution (:375, 383).  The modulated input, the
+    convolution output before demodulation and the pre-activation are never written to memory (for the up-sampled
+    first convolution of a block the bilinear x2 + modulation prologue stays its own kernel).  First-order
+    differentiable; the backward recovers conv*d from `out` (hg_demod_noise_lrelu_bwd with conv = NULL)."""
+
+    @staticmethod
+    def forward(ctx, x, style, weight, nzt, wn, bn, demod, upsample, act):
+        from . import conv as C
+        _need_gpu(x, 'modconv_stage')
+        x, style, w = _f32c(x.detach()), _f32c(style.detach()), _f32c(weight.detach())
+        B, K, H, W = x.shape
+        N, _, k, _ = w.shape
+        s1 = style + 1.0
+        if upsample:
+            with torch.cuda.device(x.device):
+                xin = torch.empty((B, K, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+                check(lib.hg_modulate_fwd(x.data_ptr(), style.data_ptr(), xin.data_ptr(), B, K, H, W, 1, _st(x)),
+                      'hg_modulate_fwd')
+            iscale = None
+        else:
+            xin, iscale = x, s1
+        Hi, Wi = xin.shape[2], xin.shape[3]
+        d = None
+        if demod:
+            wsq = w.pow(2).sum(dim=(2, 3))
+            d = torch.rsqrt(torch.mm(s1 * s1, wsq.t()) + 1e-8)
+        if act:
+            nzt_, wn_, bn_ = _f32c(nzt.detach()), _f32c(wn.detach().reshape(-1)), _f32c(bn.detach())
+            S = nzt_.shape[-1]
+        else:
+            nzt_ = wn_ = bn_ = None
+            S = 0
+        wt = C.pack_weights(w, C.PACK_FWD)
+        with torch.cuda.device(x.device):
+            out = torch.empty((B, N, Hi, Wi), dtype=torch.float32, device=x.device)
+            nb = lib.hg_conv2d_workspace_bytes(B, K, N, Hi, Wi, k, 1, 0)
+            ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
+            p = lambda t: None if t is None else t.data_ptr()
+            check(lib.hg_modconv2d_fwd(xin.data_ptr(), wt.data_ptr(), out.data_ptr(), p(iscale), p(d), p(bn_), p(wn_),
+                                       p(nzt_), S, 0.2 if act else 0.0, B, K, N, Hi, Wi, k, p(ws), nb, _st(x)),
+                  'hg_modconv2d_fwd')
+        ctx.save_for_backward(x, xin if upsample else None, style, w, d, out, nzt_, wn_, bn_)
+        ctx.cfg = (bool(demod), bool(upsample), bool(act))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import conv as C
+        x, xin, style, w, d, out, nzt_, wn_, bn_ = ctx.saved_tensors
+        demod, upsample, act = ctx.cfg
+        g = _f32c(g.detach())
+        B, K, H, W = x.shape
+        N, _, k, _ = w.shape
+        s1 = style + 1.0
+        if xin is None:
+            xin = x
+        Hi, Wi = xin.shape[2], xin.shape[3]
+        gwn = gbn = gd = None
+        with torch.cuda.device(x.device):
+            if act:
+                S = nzt_.shape[-1]
+                gconv = torch.empty_like(out)
+                gdr = torch.empty((B, N), dtype=torch.float32, device=x.device) if d is not None else None
+                gw_p = torch.empty((B, N), dtype=torch.float32, device=x.device)
+                gb_p = torch.empty((B, N), dtype=torch.float32, device=x.device)
+                ws, n = _ws(out, B, N, Hi, Wi)
+                check(lib.hg_demod_noise_lrelu_bwd(g.data_ptr(), out.data_ptr(), None,
+                                                   None if d is None else d.data_ptr(), nzt_.data_ptr(), wn_.data_ptr(),
+                                                   bn_.data_ptr(), gconv.data_ptr(),
+                                                   None if gdr is None else gdr.data_ptr(), gw_p.data_ptr(),
+                                                   gb_p.data_ptr(), B, N, Hi, S, ws.data_ptr(), n, _st(x)),
+                      'hg_demod_noise_lrelu_bwd')
+                gwn, gbn = gw_p.sum(0).reshape(-1, 1), gb_p.sum(0)
+                if d is not None:
+                    gd = gdr / d
+            else:
+                if d is not None:
+                    raise RuntimeError('modconv_stage: demodulation without activation is not implemented')
+                gconv = g
+            t = C.conv_dgrad_packed(gconv, C.pack_weights(w, C.PACK_DGRAD), K, Hi, Wi, k)
+            gx = torch.empty_like(x)
+            gs = torch.empty_like(style)
+            ws, n = _ws(x, B, K, H, W)
+            check(lib.hg_modulate_bwd(t.data_ptr(), x.data_ptr(), style.data_ptr(), gx.data_ptr(), gs.data_ptr(),
+                                      B, K, H, W, int(upsample), ws.data_ptr(), n, _st(x)), 'hg_modulate_bwd')
+            gw = C.conv_wgrad(xin, gconv, k, iscale=None if upsample else s1)
+        if d is not None:
+            wsq = w.pow(2).sum(dim=(2, 3))
+            gq = gd * (-0.5) * d * d * d
+            gs = gs + 2.0 * s1 * torch.mm(gq, wsq)
+            gw = gw + 2.0 * w * torch.mm(gq.t(), s1 * s1)[:, :, None, None]
+        return gx, gs, gw, None, gwn, gbn, None, None, None
+
+
+def modconv_stage(x, style, weight, nzt=None, wn=None, bn=None, demod=True, upsample=False, act=True):
+    """act(demod * conv(up?(x)*(style+1), weight) + wn*nzt + bn) -- see _ModConvStage."""
+    return _ModConvStage.apply(x, style, weight, nzt, wn, bn, demod, upsample, act)

@@ -41,6 +41,19 @@ int hg_conv2d_fwd(const float *in, const float *wt, float *out, const float *isc
                   const float *bias, int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
                   int32_t stride, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The generator's modulated convolution stage in ONE launch (Conv2DMod.forward + noise + LeakyReLU of
+ * GeneratorBlock.forward, histoGAN/histoGAN.py:420-440 and :465-476), stride 1:
+ *   out[b,n,y,x] = lrelu_slope( oscale[b,n] * sum_{k,dy,dx} iscale[b,k]*in[b,k,y+dy-p,x+dx-p]*Wt[dy*ksize+dx][k][n]
+ *                               + bias[n] + noise_w[n] * noise_img[b,y,x] )
+ *   iscale = style+1 (modulation), oscale = demodulation coefficient, bias / noise_w = to_noise Linear(1,N) bias /
+ *   weight, noise_img (B, noise_S, noise_S) with noise_S >= H, W (the noise image, already transposed as the
+ *   reference's permute requires, see hg_nets.h), lrelu_slope 0 = no activation.  Every pointer but in/wt/out may be
+ *   NULL (noise_w and noise_img only together).  Workspace as hg_conv2d_workspace_bytes(..., stride 1, dgrad 0). */
+int hg_modconv2d_fwd(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
+                     const float *bias, const float *noise_w, const float *noise_img, int32_t noise_S,
+                     float lrelu_slope, int32_t B, int32_t K, int32_t N, int32_t H, int32_t W, int32_t ksize,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
 /* Scratch for hg_conv2d_fwd (dgrad = 0) / hg_conv2d_dgrad (dgrad = 1) with the same B,K,N,Hi,Wi,ksize,stride:
  * launches with few output pixels and many channels (the 2x2 ... 8x8 maps) split the reduction over K into
  * slabs that a second kernel sums in fixed order.  0 = none needed; workspace may also be NULL (no K split). */

@@ -44,11 +44,13 @@ int hg_demod_noise_lrelu_fwd(const float *conv, const float *d, const float *nzt
                              const float *bn, float *out, int32_t B, int32_t O, int32_t H, int32_t S,
                              void *stream);
 /* m = gout * (out > 0 ? 1 : 0.2):  gconv = m * d;  gd[b,o] = sum m*conv  (gd may be NULL when d is);
- * gwn_part[b,o] = sum m * nzt[b,i,j];  gbn_part[b,o] = sum m   (caller sums the parts over b). */
+ * gwn_part[b,o] = sum m * nzt[b,i,j];  gbn_part[b,o] = sum m   (caller sums the parts over b).
+ * conv may be NULL (the fused forward hg_modconv2d_fwd never stores it): then wn, bn (O) are needed, conv*d is
+ * recovered from out, and gd[b,o] = sum m*conv*d  (the caller divides by d). */
 int hg_demod_noise_lrelu_bwd(const float *gout, const float *out, const float *conv, const float *d,
-                             const float *nzt, float *gconv, float *gd, float *gwn_part, float *gbn_part,
-                             int32_t B, int32_t O, int32_t H, int32_t S, void *workspace, size_t workspace_bytes,
-                             void *stream);
+                             const float *nzt, const float *wn, const float *bn, float *gconv, float *gd,
+                             float *gwn_part, float *gbn_part, int32_t B, int32_t O, int32_t H, int32_t S,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* out[c] = sum_{b,p} g[b,c,p]: the bias gradient of a convolution (nn.Conv2d bias, histoGAN/histoGAN.py:510-518). */
 int hg_channel_sum(const float *g, float *out, int32_t B, int32_t C, int32_t HW, void *workspace,

@@ -305,3 +305,45 @@ def test_channel_sum_matches_torch(shape, gpu_device):
     out = ops.channel_sum(g)
     assert relmax(out.cpu().numpy(), ref.cpu().numpy()) <= 1e-6
     assert torch.equal(out, ops.channel_sum(g))     # deterministic
+
+
+@pytest.mark.parametrize('K,N,H,up,demod,act', [(6, 10, 8, False, True, True), (5, 7, 4, True, True, True),
+                                                 (16, 3, 16, False, False, False), (40, 70, 16, False, True, True),
+                                                 (8, 8, 32, True, True, True)])
+def test_modconv_stage_matches_unfused(K, N, H, up, demod, act, gpu_device):
+    """hg_modconv2d_fwd (modulation + conv + demodulation + noise + lrelu in one launch) and its backward against the
+    reference expression of Conv2DMod.forward + GeneratorBlock noise/activation (histoGAN/histoGAN.py:420-440, 465-476)
+    evaluated in fp64 with per-sample weights and a grouped convolution, as the reference does."""
+    from histogan_amd import ops
+    torch.manual_seed(7)
+    B, S, k = 3, 64, 3 if act else 1
+    x = torch.randn(B, K, H, H, device=gpu_device, requires_grad=True)
+    y = (0.3 * torch.randn(B, K, device=gpu_device)).requires_grad_(True)
+    w = (torch.randn(N, K, k, k, device=gpu_device) / (K * k * k) ** 0.5).requires_grad_(True)
+    inoise = torch.rand(B, S, S, 1, device=gpu_device)
+    lin = torch.nn.Linear(1, N).to(gpu_device)
+    Ho = 2 * H if up else H
+
+    def reference(x, y, w, lw, lb):
+        xd = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) if up else x
+        wts = w[None] * (y[:, None, :, None, None] + 1)
+        if demod:
+            wts = wts * torch.rsqrt((wts ** 2).sum(dim=(2, 3, 4), keepdim=True) + 1e-8)
+        o = F.conv2d(xd.reshape(1, -1, Ho, Ho), wts.reshape(B * N, K, k, k), padding=k // 2, groups=B).reshape(B, N, Ho, Ho)
+        if act:
+            noise = F.linear(inoise[:, :Ho, :Ho, :].to(x.dtype), lw, lb).permute(0, 3, 2, 1)
+            o = F.leaky_relu(o + noise, 0.2)
+        return o
+
+    nzt = inoise[..., 0].transpose(1, 2).contiguous()
+    out = ops.modconv_stage(x, y, w, nzt if act else None, lin.weight if act else None, lin.bias if act else None,
+                            demod=demod, upsample=up, act=act)
+    dd = [t.detach().double().requires_grad_(True) for t in (x, y, w, lin.weight, lin.bias)]
+    ref = reference(*dd)
+    assert relmax(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 1e-5
+    go = torch.randn_like(out)
+    ins = [x, y, w] + ([lin.weight, lin.bias] if act else [])
+    gm = torch.autograd.grad(out, ins, go)
+    gr = torch.autograd.grad(ref, dd[:len(ins)], go.double())
+    for a, b in zip(gm, gr):
+        assert relmax(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4
