@@ -78,6 +78,8 @@ def _load():
     lib.hg_conv_packed_elems.argtypes = [i32, i32, i32, i32]
     lib.hg_conv_pack_weights.restype = ctypes.c_int
     lib.hg_conv_pack_weights.argtypes = [vp, vp, i32, i32, i32, i32, vp]
+    lib.hg_conv_pack_weights_both.restype = ctypes.c_int
+    lib.hg_conv_pack_weights_both.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.hg_conv2d_fwd.restype = ctypes.c_int
     lib.hg_conv2d_fwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]
     lib.hg_modconv2d_fwd.restype = ctypes.c_int
@@ -100,7 +102,7 @@ EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg
            'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd',
            'hg_modulate_fwd', 'hg_modulate_bwd', 'hg_demod_noise_lrelu_fwd', 'hg_demod_noise_lrelu_bwd',
            'hg_diffgrad_step', 'hg_ema_update', 'hg_nets_workspace_bytes', 'hg_channel_sum',
-           'hg_conv_packed_elems', 'hg_conv_pack_weights', 'hg_conv2d_fwd', 'hg_modconv2d_fwd', 'hg_conv2d_workspace_bytes', 'hg_conv2d_dgrad',
+           'hg_conv_packed_elems', 'hg_conv_pack_weights', 'hg_conv_pack_weights_both', 'hg_conv2d_fwd', 'hg_modconv2d_fwd', 'hg_conv2d_workspace_bytes', 'hg_conv2d_dgrad',
            'hg_conv2d_wgrad_workspace_bytes',
            'hg_conv2d_wgrad')
 

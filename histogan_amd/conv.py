@@ -91,10 +91,22 @@ def pack_weights(w, mode):
         hit = _cache.get((key, mode))
         if hit is not None and hit[0] == (_generation, w._version):
             return hit[1]
-        wt = _pack_weights(w, mode)
-        _cache[(key, mode)] = ((_generation, w._version), wt)
-        return wt
+        # a registered (training) weight needs both operands once per optimizer step: one read, two writes
+        both = _pack_both(w)
+        for m in (PACK_FWD, PACK_DGRAD):
+            _cache[(key, m)] = ((_generation, w._version), both[m])
+        return both[mode]
     return _pack_weights(w, mode)
+
+
+def _pack_both(w):
+    Co, Ci, k, _ = w.shape
+    with torch.cuda.device(w.device):
+        wf = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_FWD), dtype=torch.float32, device=w.device)
+        wd = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_DGRAD), dtype=torch.float32, device=w.device)
+        check(lib.hg_conv_pack_weights_both(w.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, _st(w)),
+              'hg_conv_pack_weights_both')
+    return {PACK_FWD: wf, PACK_DGRAD: wd}
 
 
 def _pack_weights(w, mode):

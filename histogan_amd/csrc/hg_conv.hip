@@ -634,6 +634,33 @@ __global__ __launch_bounds__(256) void k_pack(const float *__restrict__ w, float
   }
 }
 
+// both packings from ONE read of the weights (the training step needs the forward and the data-gradient operand of
+// every convolution once per optimizer step)
+template <int TAPS>
+__global__ __launch_bounds__(256) void k_pack_both(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wd,
+                                                   int Co, int Ci, int Kpf, int Npf, int Kpd, int Npd) {
+  constexpr int RW = 32 * TAPS;
+  __shared__ float tile[32][RW + 1];
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  for (int e = threadIdx.x; e < 32 * RW; e += 256) {
+    const int i = e / RW, q = e % RW;
+    const int co = co0 + i, ci = ci0 + q / TAPS;
+    tile[i][q] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci0) * TAPS + q] : 0.f;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * RW; e += 256) {
+    const int b = e & 31, a_ = (e >> 5) & 31, t = e >> 10;
+    {  // forward: Wt[t][ci][co]
+      const int kk = ci0 + a_, nn = co0 + b;
+      if (kk < Kpf && nn < Npf) wf[((size_t)t * Kpf + kk) * Npf + nn] = tile[b][a_ * TAPS + t];
+    }
+    {  // data gradient: Wt[t][co][ci] with flipped taps
+      const int kk = co0 + a_, nn = ci0 + b;
+      if (kk < Kpd && nn < Npd) wd[((size_t)t * Kpd + kk) * Npd + nn] = tile[a_][b * TAPS + (TAPS - 1 - t)];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 inline int ceil_log2(int v) {
   int l = 0;
@@ -922,6 +949,21 @@ size_t hg_conv2d_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t Hi, in
   }
   const int Ho = out_size(Hi, stride), Wo = out_size(Wi, stride);
   return conv_ws_bytes(plan_conv(B, K, N, Ho, Wo, stride, 1, true), B, N, Ho, Wo);
+}
+
+int hg_conv_pack_weights_both(const float *w, float *wt_fwd, float *wt_dgrad, int32_t Co, int32_t Ci, int32_t ksize,
+                              void *stream) {
+  if (!w || !wt_fwd || !wt_dgrad || Co <= 0 || Ci <= 0 || (ksize != 1 && ksize != 3)) return HG_EINVAL;
+  const int Kpf = round_up(Ci, 16), Npf = round_up(Co, 128), Kpd = round_up(Co, 16), Npd = round_up(Ci, 128);
+  // the grid covers both padded extents so that all padding is written
+  const dim3 grid((unsigned)(round_up(Ci, 128) / 32), (unsigned)(round_up(Co, 128) / 32));
+  hipStream_t st = (hipStream_t)stream;
+  if (ksize == 3)
+    hipLaunchKernelGGL(k_pack_both<9>, grid, dim3(256), 0, st, w, wt_fwd, wt_dgrad, Co, Ci, Kpf, Npf, Kpd, Npd);
+  else
+    hipLaunchKernelGGL(k_pack_both<1>, grid, dim3(256), 0, st, w, wt_fwd, wt_dgrad, Co, Ci, Kpf, Npf, Kpd, Npd);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
 }
 
 static int conv2d_fwd_impl(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,

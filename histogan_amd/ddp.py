@@ -41,6 +41,7 @@ class GradAllReduce:
         self._work = []
 
     def start(self):
+        self.flat.gather()
         if not is_dist():
             return
         g = self.flat.grad

@@ -45,14 +45,36 @@ class FlatParams:
             off += n
 
     def zero_grad(self):
-        # keep the views alive: autograd accumulates in place into an existing .grad
-        self.grad.zero_()
+        """Drop the parameter gradients.  With `.grad = None` autograd's AccumulateGrad hands over the incoming gradient
+        tensor instead of launching one `grad += new` kernel per parameter into a zeroed buffer; `gather()` then
+        copies all of them into the flat gradient buffer with a few multi-tensor launches."""
+        for p in self.params:
+            p.grad = None
+        self._gathered = False
+
+    def gather(self):
+        """Make `self.grad` (and every `p.grad`, re-pointed to its slice) hold the gradients of the last backward
+        passes; parameters that received none get zeros.  Idempotent."""
+        if getattr(self, '_gathered', True):
+            return
+        dst, src, missing = [], [], []
         off = 0
+        base = self.grad.data_ptr()
         for p in self.params:
             n = p.numel()
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
-                p.grad = self.grad[off:off + n].view(p.shape)
+            v = self.grad[off:off + n].view(p.shape)
+            if p.grad is None:
+                missing.append(v)
+            elif p.grad.data_ptr() != base + 4 * off:
+                dst.append(v)
+                src.append(p.grad)
+            p.grad = v
             off += n
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if missing:
+            torch._foreach_zero_(missing)
+        self._gathered = True
 
 
 class DiffGrad:
@@ -72,6 +94,7 @@ class DiffGrad:
 
     def step(self):
         f = self.flat
+        f.gather()
         if not f.data.is_cuda:
             raise RuntimeError('DiffGrad: parameters are not on a GPU; no CPU implementation')
         self.step_count += 1

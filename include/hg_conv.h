@@ -33,6 +33,10 @@ size_t hg_conv_packed_elems(int32_t Co, int32_t Ci, int32_t ksize, int32_t mode)
 int hg_conv_pack_weights(const float *w, float *wt, int32_t Co, int32_t Ci, int32_t ksize, int32_t mode,
                          void *stream);
 
+/* Both packings from one read of w (wt_fwd: hg_conv_packed_elems(.., HG_CONV_PACK_FWD) floats, wt_dgrad: .._DGRAD). */
+int hg_conv_pack_weights_both(const float *w, float *wt_fwd, float *wt_dgrad, int32_t Co, int32_t Ci, int32_t ksize,
+                              void *stream);
+
 /* Output of the convolution (stride 1 or 2; stride 2 needs ksize 3), p = ksize/2, zeros outside the image:
  *   out[b,n,y,x] = oscale[b,n] * sum_{k,dy,dx} iscale[b,k] * in[b,k,y*stride+dy-p,x*stride+dx-p] * Wt[dy*ksize+dx][k][n] + bias[n]
  *   in (B,K,Hi,Wi), out (B,N,Ho,Wo) with Ho = (Hi-1)/stride + 1;  wt packed with HG_CONV_PACK_FWD.

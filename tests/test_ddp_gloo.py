@@ -38,6 +38,7 @@ def _worker(rank, world, port, q):
         flat.zero_grad()
         x = torch.ones(4, 5)
         (net(x).sum() * (rank + 1)).backward()
+        flat.gather()                                       # autograd's tensors -> the flat buffer
         local = flat.grad.clone()
         red.start(); red.finish()
         both = [torch.empty_like(local) for _ in range(world)]

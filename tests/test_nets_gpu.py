@@ -152,7 +152,7 @@ def test_diffgrad_and_ema_match_oracle(gpu_device):
         opt.zero_grad()
         gs = [torch.randn_like(r) * (0.1 + it) for r in ref]
         for p, gr in zip(ps, gs):
-            p.grad.copy_(gr.to(gpu_device))
+            p.grad = gr.to(gpu_device)          # as autograd leaves it; DiffGrad.step gathers into the flat buffer
         opt.step()
         for r, gr, stt in zip(ref, gs, states):
             N.diffgrad_step(r, gr, stt, lr=2e-4, betas=(0.5, 0.9))
