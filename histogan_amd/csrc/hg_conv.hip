@@ -719,7 +719,7 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
   if (N <= 16 && wide256) { p.tile = TILE_16x256; return p; }
   if (N <= 32 && wide256) { p.tile = TILE_32x256; return p; }
   if (N <= 64 && wide256 && blocks(64, 256) >= 384) { p.tile = TILE_64x256; return p; }
-  if (N > 64 && wide128 && blocks(128, 128) >= 384) { p.tile = TILE_128x128; return p; }
+  if (N > 64 && wide128 && blocks(128, 128) >= 256) { p.tile = TILE_128x128; return p; }
   p.tile = TILE_64x64;
   // pixel tiles of the 64x64 shape: images are grouped when the map is smaller than the tile
   const int tw = Wc <= 2 && IS == 1 ? 2 : (Wc <= 4 ? 4 : (Wc <= 8 ? 8 : (Wc <= 16 ? 16 : 32)));
@@ -728,7 +728,7 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
   const int ni = 64 / (tw * th);
   const long long nblk = (long long)((Wc + tw - 1) / tw) * ((Hc + th - 1) / th) * ((B + ni - 1) / ni) * ((N + 63) / 64);
   const int kc = IS == 2 ? 8 : 2 * HG_CONV_KC, nchunks = (K + kc - 1) / kc;
-  if (have_ws && os == 1 && nblk < 256 && nchunks >= 8) {
+  if (have_ws && os == 1 && nblk < 384 && nchunks >= 8) {
     int ks = (int)((512 + nblk - 1) / nblk);
     if (ks > nchunks / 4) ks = nchunks / 4;
     if (ks > 32) ks = 32;
