@@ -1,0 +1,63 @@
+"""Trainer around the step: image-folder source with GPU target histograms, checkpoint
+save/load with the reference's state_dict key names, evaluate() grid output (row f-4)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN_DIR
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_folder(path, n=6, size=40):
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    os.makedirs(path, exist_ok=True)
+    for i in range(n):
+        arr = (rs.rand(size + i, size + 2 * i, 3) * 255).astype(np.uint8)       # different sizes, like a real folder
+        Image.fromarray(arr).save(os.path.join(path, f'im{i}.png' if i % 2 else f'im{i}.jpg'))
+
+
+def test_folder_source_checkpoint_and_evaluate(gpu_device, tmp_path):
+    from histoGAN import Trainer
+    folder = str(tmp_path / 'imgs')
+    _make_folder(folder)
+    kw = dict(batch_size=2, hist_bin=16, hist_insz=32, hist_resizing='interpolation', save_every=1000)
+    tr = Trainer('io', str(tmp_path / 'results'), str(tmp_path / 'models'), 32, 2, **kw)
+    tr.set_data_src(folder)
+    batch = next(tr.loader)
+    assert batch['images'].shape == (2, 3, 32, 32) and batch['images'].is_cuda
+    assert batch['histograms'].shape == (2, 3, 16, 16)
+    assert torch.allclose(batch['histograms'].sum(dim=(1, 2, 3)), torch.ones(2, device=gpu_device), atol=1e-4)
+    tr.run_evaluate = False
+    tr.train(alpha=2)                    # step 0: saves checkpoint 0 (steps % save_every == 0), GP + PL step
+    tr.train(alpha=2)
+    assert tr.steps == 2 and np.isfinite(tr.d_loss) and np.isfinite(tr.g_loss)
+    ckpt = tmp_path / 'models' / 'io' / 'model_0.pt'
+    assert ckpt.exists() and (tmp_path / 'models' / 'io' / '.config.json').exists()
+
+    # checkpoint keys == the reference's HistoGAN.state_dict() layout (golden file holds G./D. names of the reference)
+    sd = torch.load(str(ckpt), map_location='cpu')
+    gold = np.load(os.path.join(GOLDEN_DIR, 'nets_small.npz'))
+    ref_g = {k[2:] for k in gold.files if k.startswith('G/')}
+    ref_d = {k[2:] for k in gold.files if k.startswith('D/')}
+    mine_g = {k[2:] for k in sd if k.startswith('G.')}
+    mine_d = {k[2:] for k in sd if k.startswith('D.')}
+    # same parameter names per block (the golden nets are smaller: compare the name patterns of block 0 and the tails)
+    pat = lambda names: {n for n in names if n.startswith('blocks.0.') or not n.startswith('blocks.')}
+    assert pat(ref_g) == pat(mine_g)
+    assert pat(ref_d) == pat(mine_d)
+    assert {k.split('.')[0] for k in sd} >= {'S', 'H', 'G', 'D', 'SE', 'HE', 'GE'}
+
+    # resume in a fresh trainer, same weights, then evaluate() writes the EMA sample grid
+    tr2 = Trainer('io', str(tmp_path / 'results'), str(tmp_path / 'models'), 32, 2, **kw)
+    tr2.load(-1)
+    assert tr2.steps == 0
+    for (k1, v1), (k2, v2) in zip(sorted(tr2.GAN.state_dict().items()), sorted(sd.items())):
+        assert k1 == k2 and torch.equal(v1.cpu(), v2)
+    tr2.set_data_src(folder)
+    imgs = tr2.evaluate(num=7, num_image_tiles=2)
+    assert imgs.shape == (4, 3, 32, 32) and float(imgs.min()) >= 0.0 and float(imgs.max()) <= 1.0
+    assert (tmp_path / 'results' / 'io' / '7-ema.jpg').exists()
