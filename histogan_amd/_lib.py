@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_PKG, 'libhistogan_hip' + ('_' + _TAG if _TAG else '') +
 
 HG_METHOD = {'thresholding': 0, 'RBF': 1, 'inverse-quadratic': 2}
 HG_RESIZE_NONE, HG_RESIZE_BILINEAR, HG_RESIZE_SAMPLING = 0, 1, 2
+HG_PROJ = {'rgbuv': 0, 'rgchroma': 1, 'direct': 2}
 
 
 class HgHistParams(ctypes.Structure):
@@ -29,6 +30,7 @@ class HgHistParams(ctypes.Structure):
         ('sigma', ctypes.c_double),
         ('intensity_scale', ctypes.c_int32),
         ('green_only', ctypes.c_int32),
+        ('projection', ctypes.c_int32),
     ]
 
 

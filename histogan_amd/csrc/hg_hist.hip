@@ -55,6 +55,7 @@ struct DevParams {
   int Hs, Ws, mode;
   const int *rows, *cols;
   int h, P, method, intensity, green;
+  int proj;                 // HG_PROJ_*: 0 RGB-uv (3 planes), 1 rg-chroma, 2 direct (Lab): one plane, run as `green`
   int npix;
   double lo, hi, step;      // bins: i*step+lo, last == hi  (np.linspace)
   double inv_sigma_d;       // (double)(float)(1/sigma) -- pairs with inv_sigma
@@ -112,6 +113,20 @@ __device__ __forceinline__ void sample_rgb(const DevParams &P, const float *xb, 
 // Stage 1 (projection), RGBuvHistBlock.py:104-115: three logs and three chroma differences.
 __device__ __forceinline__ void project(const DevParams &P, float r, float g, float b, float &a,
                                         float &bb, float &c, float &iy) {
+  if (P.proj == HG_PROJ_RGCHROMA) {
+    // rgChromaHistBlock.py:100-110: (u, v) = (R, G) / (R+G+B + eps), weight Iy.  The single plane runs through the
+    // `green` path, which bins (-a, c): a = -u, c = v.
+    const float s = __fadd_rn(__fadd_rn(__fadd_rn(r, g), b), kEps);
+    a = -__fdiv_rn(r, s); c = __fdiv_rn(g, s); bb = 0.f;
+    iy = P.intensity ? __fsqrt_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r, r), __fmul_rn(g, g)), __fmul_rn(b, b)), kEps)) : 1.f;
+    return;
+  }
+  if (P.proj == HG_PROJ_DIRECT) {
+    // LabHistBlock.py:102-109: (u, v) = channels (1, 2), weight = channel 0 (L) when intensity_scale
+    a = -g; c = b; bb = 0.f;
+    iy = P.intensity ? r : 1.f;
+    return;
+  }
   // The reference's CPU logf is correctly rounded for >99.9% of inputs (probe); an fp64 log rounded
   // to fp32 reproduces it, where a 1-ulp device logf would perturb u by ~1e-7 and, through the
   // ~50x sensitivity of k at |u-b| = sigma, move single weights by ~5e-6.  3 fp64 logs per pixel
@@ -347,15 +362,8 @@ __global__ __launch_bounds__(256) void k_hist_normalize(float *__restrict__ hist
 // Chain rule from (dL/da, dL/db, dL/dc, dL/dIy) to the pixel and the store:
 //   dL_R = da+db, dL_G = -da+dc, dL_B = -db-dc,  dx_c = dL_c/(x_c+1e-6) + dIy x_c/Iy,
 // masked by the clamp of RGBuvHistBlock.py:76 when written straight to grad_x.
-__device__ __forceinline__ void store_pixel_grad(const DevParams &P, const float *xb, int b, int n, float r_,
-                                                 float g_, float b_, float iy, float da, float db, float dc,
-                                                 float dIy, float *gdst) {
-  const float dLr = da + db, dLg = dc - da, dLb = -db - dc;
-  float dr = dLr / (r_ + kEps), dg = dLg / (g_ + kEps), dbl = dLb / (b_ + kEps);
-  if (P.intensity) {
-    const float w = dIy / iy;
-    dr = fmaf(w, r_, dr); dg = fmaf(w, g_, dg); dbl = fmaf(w, b_, dbl);
-  }
+__device__ __forceinline__ void store_rgb_grad(const DevParams &P, const float *xb, int b, int n, float dr, float dg,
+                                               float dbl, float *gdst) {
   if (P.mode == HG_RESIZE_NONE) {
     const int ys = n / P.Ws, xs = n - ys * P.Ws;
     const long long xo = ys * P.sh + xs * P.sw;
@@ -369,6 +377,38 @@ __device__ __forceinline__ void store_pixel_grad(const DevParams &P, const float
     float *gb = gdst + ((long long)b * 3) * P.npix + n;
     gb[0] = dr; gb[P.npix] = dg; gb[2LL * P.npix] = dbl;
   }
+}
+
+__device__ __forceinline__ void store_pixel_grad(const DevParams &P, const float *xb, int b, int n, float r_,
+                                                 float g_, float b_, float iy, float da, float db, float dc,
+                                                 float dIy, float *gdst) {
+  const float dLr = da + db, dLg = dc - da, dLb = -db - dc;
+  float dr = dLr / (r_ + kEps), dg = dLg / (g_ + kEps), dbl = dLb / (b_ + kEps);
+  if (P.intensity) {
+    const float w = dIy / iy;
+    dr = fmaf(w, r_, dr); dg = fmaf(w, g_, dg); dbl = fmaf(w, b_, dbl);
+  }
+  store_rgb_grad(P, xb, b, n, dr, dg, dbl, gdst);
+}
+
+// Chain rule of the one-plane projections: dU = dL/du, dV = dL/dv, dW = dL/dweight
+__device__ __forceinline__ void store_pixel_grad_proj(const DevParams &P, const float *xb, int b, int n, float r_,
+                                                      float g_, float b_, float iy, float dU, float dV, float dW,
+                                                      float *gdst) {
+  float dr, dg, dbl;
+  if (P.proj == HG_PROJ_RGCHROMA) {
+    // u = r/S, v = g/S, S = r+g+b+eps:  du/dr = 1/S - r/S^2, du/dg = du/db = -r/S^2 (same for v with g)
+    const float S = ((r_ + g_) + b_) + kEps, inv = 1.f / S;
+    const float common = -(dU * r_ + dV * g_) * inv * inv;
+    dr = fmaf(dU, inv, common); dg = fmaf(dV, inv, common); dbl = common;
+    if (P.intensity) {
+      const float w = dW / iy;
+      dr = fmaf(w, r_, dr); dg = fmaf(w, g_, dg); dbl = fmaf(w, b_, dbl);
+    }
+  } else {  // HG_PROJ_DIRECT: weight = channel 0, (u, v) = channels (1, 2)
+    dr = P.intensity ? dW : 0.f; dg = dU; dbl = dV;
+  }
+  store_rgb_grad(P, xb, b, n, dr, dg, dbl, gdst);
 }
 
 // bin permutation shared by the MFMA K index and the accumulator row index (see k_hist_bwd)
@@ -646,7 +686,10 @@ __global__ __launch_bounds__(64) void k_hist_bwd_generic(const DevParams P, cons
   const float da = iy * (gu[0] - gu[1]), db = iy * (gv[0] - gu[2]), dc = iy * (gv[1] - gv[2]);
   const float dIy = P.intensity ? isum : 0.f;
   if (valid) {
-    store_pixel_grad(P, xb, b, n, r_, g_, b_, iy, da, db, dc, dIy, gdst);
+    if (P.proj != HG_PROJ_RGBUV)   // one plane, binned as (u, v) = (-a, c): gu[1] = dL/du, gv[1] = dL/dv (before the weight)
+      store_pixel_grad_proj(P, xb, b, n, r_, g_, b_, iy, iy * gu[1], iy * gv[1], dIy, gdst);
+    else
+      store_pixel_grad(P, xb, b, n, r_, g_, b_, iy, da, db, dc, dIy, gdst);
     if (P.mode == HG_RESIZE_NONE)
       for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
   }
@@ -742,6 +785,7 @@ int validate(const hg_hist_params *p) {
   if (!(p->hi >= p->lo)) return HG_EINVAL;
   if (p->method != HG_METHOD_THRESHOLDING && !(p->sigma > 0.0)) return HG_EINVAL;
   if ((long long)p->Hs * p->Ws > 0x7fffffffLL) return HG_EINVAL;
+  if (p->projection < 0 || p->projection > 2) return HG_EINVAL;
   return HG_OK;
 }
 
@@ -752,7 +796,7 @@ Plan make_plan(const hg_hist_params *p) {
   pl.nbd = (p->h + pl.BLK - 1) / pl.BLK;
   pl.HP = pl.nbd * pl.BLK;
   const long long npix = (long long)p->Hs * p->Ws;
-  const int P = p->green_only ? 1 : 3;
+  const int P = (p->green_only || p->projection) ? 1 : 3;
   // forward: aim at ~2 workgroups per CU (256 CUs), >= 64 pixels per wave
   const long long wg_fixed = (long long)p->B * pl.nbd * pl.nbd;
   long long target = 512;
@@ -783,7 +827,7 @@ Plan make_plan(const hg_hist_params *p) {
   pl.S_bwd = (int)Sb;
   pl.rounds = (int)rpw;
   // generic backward only (h > 64 or asymmetric boundary): Ghat in natural layout
-  pl.gh_bytes = ((p->lo != -p->hi) || pl.nbd != 1) ? ((size_t)p->B * n_per_img * sizeof(float) + 255) / 256 * 256 : 256;
+  pl.gh_bytes = ((p->lo != -p->hi) || pl.nbd != 1 || p->projection) ? ((size_t)p->B * n_per_img * sizeof(float) + 255) / 256 * 256 : 256;
   pl.gxs_bytes = (p->resize_mode == HG_RESIZE_NONE) ? 0 : ((size_t)p->B * 3 * npix * sizeof(float) + 255) / 256 * 256;
   return pl;
 }
@@ -793,8 +837,9 @@ DevParams make_dev(const hg_hist_params *p) {
   d.B = p->B; d.C = p->C; d.H = p->H; d.W = p->W;
   d.sb = p->stride_b; d.sc = p->stride_c; d.sh = p->stride_h; d.sw = p->stride_w;
   d.Hs = p->Hs; d.Ws = p->Ws; d.mode = p->resize_mode; d.rows = p->row_idx; d.cols = p->col_idx;
-  d.h = p->h; d.P = p->green_only ? 1 : 3; d.method = p->method;
-  d.intensity = p->intensity_scale ? 1 : 0; d.green = p->green_only ? 1 : 0;
+  d.proj = p->projection;
+  d.h = p->h; d.P = (p->green_only || p->projection) ? 1 : 3; d.method = p->method;
+  d.intensity = p->intensity_scale ? 1 : 0; d.green = (p->green_only || p->projection) ? 1 : 0;
   d.npix = p->Hs * p->Ws;
   d.lo = p->lo; d.hi = p->hi; d.step = (p->h > 1) ? (p->hi - p->lo) / (double)(p->h - 1) : 0.0;
   const double sigma = (p->method == HG_METHOD_THRESHOLDING) ? 1.0 : p->sigma;
@@ -917,7 +962,7 @@ int hg_rgbuv_hist_bwd(const hg_hist_params *p, const float *x, const float *grad
   const Plan pl = make_plan(p);
   if (workspace_bytes < pl.gxs_bytes + pl.gh_bytes) return HG_EWORKSPACE;
   const bool sym = (p->lo == -p->hi);
-  const bool generic = !sym || pl.nbd != 1;
+  const bool generic = !sym || pl.nbd != 1 || p->projection != HG_PROJ_RGBUV;
   hipStream_t st = (hipStream_t)stream;
   const DevParams d = make_dev(p);
   float *gxs = (float *)workspace;

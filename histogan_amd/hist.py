@@ -27,12 +27,17 @@ def _sampling_idx(size, h, device):
 
 class HistConfig:
     """Immutable description of one RGBuvHistBlock (ctor args, RGBuvHistBlock.py:29-73)."""
-    __slots__ = ('h', 'insz', 'resizing', 'method', 'sigma', 'intensity_scale', 'lo', 'hi', 'green_only')
+    __slots__ = ('h', 'insz', 'resizing', 'method', 'sigma', 'intensity_scale', 'lo', 'hi', 'green_only', 'projection')
 
     def __init__(self, h=64, insz=150, resizing='interpolation', method='inverse-quadratic', sigma=0.02,
-                 intensity_scale=True, hist_boundary=None, green_only=False):
+                 intensity_scale=True, hist_boundary=None, green_only=False, projection='rgbuv'):
+        """projection: 'rgbuv' (RGBuvHistBlock, 3 planes, default boundary [-3,3]), 'rgchroma' (rgChromaHistBlock) or
+        'direct' (LabHistBlock): one plane, default boundary [0,1]."""
+        if projection not in _lib.HG_PROJ:
+            raise ValueError(f'unknown projection {projection!r}')
+        self.projection = projection
         if hist_boundary is None:
-            hist_boundary = [-3, 3]
+            hist_boundary = [-3, 3] if projection == 'rgbuv' else [0, 1]
         hb = sorted(hist_boundary)
         self.h, self.insz, self.resizing, self.method = int(h), insz, resizing, method
         self.sigma = sigma
@@ -68,6 +73,7 @@ def _make_params(x, cfg):
     p.method = _lib.HG_METHOD[cfg.method]
     p.sigma = float(cfg.sigma) if cfg.method != 'thresholding' else 1.0
     p.intensity_scale, p.green_only = int(cfg.intensity_scale), int(cfg.green_only)
+    p.projection = _lib.HG_PROJ[cfg.projection]
     return p, keep
 
 
@@ -97,7 +103,7 @@ class RGBuvHistFunction(torch.autograd.Function):
         p, keep = _make_params(x, cfg)
         fwd_b, _ = _ws_bytes(p)
         with torch.cuda.device(x.device):
-            P = 1 if cfg.green_only else 3
+            P = 1 if (cfg.green_only or cfg.projection != 'rgbuv') else 3
             out = torch.empty((p.B, P, cfg.h, cfg.h), dtype=torch.float32, device=x.device)
             sums = torch.empty((p.B,), dtype=torch.float32, device=x.device)
             ws = torch.empty((max(fwd_b, 4),), dtype=torch.uint8, device=x.device)

@@ -34,6 +34,10 @@ extern "C" {
 #define HG_METHOD_RBF 1
 #define HG_METHOD_INVERSE_QUADRATIC 2
 
+#define HG_PROJ_RGBUV 0
+#define HG_PROJ_RGCHROMA 1
+#define HG_PROJ_DIRECT 2
+
 /* stage-0 resize, RGBuvHistBlock.py:77-95 */
 #define HG_RESIZE_NONE 0      /* H<=insz and W<=insz: pixels used as they are            */
 #define HG_RESIZE_BILINEAR 1  /* F.interpolate(size=(Hs,Ws), bilinear, align_corners=False) */
@@ -55,6 +59,11 @@ typedef struct hg_hist_params {
   double sigma;           /* RBF / inverse-quadratic width (ignored for thresholding)    */
   int32_t intensity_scale;
   int32_t green_only;     /* only plane 1 (log g/r, log g/b), written at plane index 0   */
+  /* 2-D projection of a pixel (HG_PROJ_*).  0: RGB-uv log-chroma, 3 planes.  The two one-plane variants of the
+   * reference's other histogram blocks share everything else (clamp, resize, kernels, normalisation):
+   * 1: rg-chroma (u,v) = (R,G)/(R+G+B+1e-6), weight Iy   (histogram_classes/rgChromaHistBlock.py:100-141)
+   * 2: direct     (u,v) = channels (1,2), weight = channel 0  (histogram_classes/LabHistBlock.py:102-140) */
+  int32_t projection;
 } hg_hist_params;
 
 /* library / build identification */
