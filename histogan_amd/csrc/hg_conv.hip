@@ -642,12 +642,29 @@ __global__ __launch_bounds__(256) void k_pack_both(const float *__restrict__ w, 
   constexpr int RW = 32 * TAPS;
   __shared__ float tile[32][RW + 1];
   const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-  for (int e = threadIdx.x; e < 32 * RW; e += 256) {
+  if (co0 >= Co || ci0 >= Ci) {   // padding-only tile: zeros, no loads
+    for (int e = threadIdx.x; e < 32 * RW; e += 256) {
+      const int b = e & 31, a_ = (e >> 5) & 31, t = e >> 10;
+      if (ci0 + a_ < Kpf && co0 + b < Npf) wf[((size_t)t * Kpf + ci0 + a_) * Npf + co0 + b] = 0.f;
+      if (co0 + a_ < Kpd && ci0 + b < Npd) wd[((size_t)t * Kpd + co0 + a_) * Npd + ci0 + b] = 0.f;
+    }
+    return;
+  }
+  float v[4 * TAPS];   // 32*RW / 256 loads in flight (a rolled loop pays one global latency per iteration)
+#pragma unroll
+  for (int it = 0; it < 4 * TAPS; ++it) {
+    const int e = threadIdx.x + it * 256;
     const int i = e / RW, q = e % RW;
     const int co = co0 + i, ci = ci0 + q / TAPS;
-    tile[i][q] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci0) * TAPS + q] : 0.f;
+    v[it] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci0) * TAPS + q] : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < 4 * TAPS; ++it) {
+    const int e = threadIdx.x + it * 256;
+    tile[e / RW][e % RW] = v[it];
   }
   __syncthreads();
+#pragma unroll 4
   for (int e = threadIdx.x; e < 32 * RW; e += 256) {
     const int b = e & 31, a_ = (e >> 5) & 31, t = e >> 10;
     {  // forward: Wt[t][ci][co]
