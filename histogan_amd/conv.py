@@ -232,6 +232,59 @@ class _ConvWgrad(torch.autograd.Function):
         return gg, gx, None, None
 
 
+class _ConvLrelu(torch.autograd.Function):
+    """y = leaky_relu(conv(x, w) + bias, slope) in ONE launch (the epilogue of the fused-extras k_conv instantiation):
+    the `nn.Conv2d -> LeakyReLU(0.2)` pairs of DiscriminatorBlock.net (histoGAN/histoGAN.py:510-515).  The backward
+    masks the incoming gradient with aten's leaky_relu_backward on the OUTPUT (sign(y) == sign(pre-activation)), which
+    autograd can differentiate again, then continues with the bilinear conv Functions -> any-order differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, slope):
+        _check_args(x, w, stride)
+        if x.shape[1] != w.shape[1]:
+            raise ValueError(f'conv2d: x {tuple(x.shape)} does not match w {tuple(w.shape)}')
+        xc, wc = _f32c(x), _f32c(w)
+        B, K, H, W = xc.shape
+        N, k = w.shape[0], w.shape[2]
+        wt = pack_weights(wc, PACK_FWD)
+        bc = None if bias is None else _f32c(bias)
+        with torch.cuda.device(x.device):
+            out = torch.empty((B, N, _out_size(H, stride), _out_size(W, stride)), dtype=torch.float32, device=x.device)
+            if stride == 1:
+                nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, k, 1, 0)
+                ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
+                check(lib.hg_modconv2d_fwd(xc.data_ptr(), wt.data_ptr(), out.data_ptr(), None, None, _ptr(bc), None, None,
+                                           0, float(slope), B, K, N, H, W, k, _ptr(ws), nb, _st(x)), 'hg_modconv2d_fwd')
+            else:
+                raise ValueError('conv2d_lrelu: stride 1 only')
+        ctx.save_for_backward(x, w, out)
+        ctx.stride, ctx.has_bias, ctx.slope = stride, bias is not None, float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, out = ctx.saved_tensors
+        gm = torch.ops.aten.leaky_relu_backward(g, out, ctx.slope, True)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _ConvDgrad.apply(gm, w, x.shape[2], x.shape[3], ctx.stride)
+        if not _skip_wgrad:
+            if ctx.needs_input_grad[1]:
+                gw = _ConvWgrad.apply(gm, x, w.shape[2], ctx.stride)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                if torch.is_grad_enabled():
+                    gb = gm.sum(dim=(0, 2, 3))
+                else:
+                    from .ops import channel_sum
+                    gb = channel_sum(gm)
+        return gx, gw, gb, None, None
+
+
+def conv2d_lrelu(x, w, bias=None, slope=0.2):
+    """leaky_relu(F.conv2d(x, w, bias, padding=k//2), slope) as one launch (stride 1)."""
+    return _ConvLrelu.apply(x, w, bias, 1, slope)
+
+
 def conv2d(x, w, bias=None, stride=1):
     """F.conv2d(x, w, bias, stride=stride, padding=k//2) for k in {1,3} on the MFMA implicit-GEMM kernels."""
     return _Conv.apply(x, w, bias, stride)

@@ -148,3 +148,33 @@ def test_conv_rejects_cpu_and_bad_kernel(gpu_device):
     from histogan_amd.conv import conv2d
     with pytest.raises(ValueError):
         conv2d(torch.randn(1, 2, 8, 8, device=gpu_device), torch.randn(3, 2, 1, 1, device=gpu_device), None, 2)
+
+
+def test_conv2d_lrelu_and_its_double_backward(gpu_device):
+    """conv + bias + LeakyReLU in one launch (DiscriminatorBlock.net pairs) incl. the gradient-penalty pattern."""
+    from histogan_amd.conv import conv2d_lrelu, input_grads_only
+    torch.manual_seed(12)
+    B, K, N, H = 3, 6, 10, 12
+    x = torch.randn(B, K, H, H, device=gpu_device, requires_grad=True)
+    w1 = (torch.randn(N, K, 3, 3, device=gpu_device) / (K * 9) ** 0.5).requires_grad_(True)
+    b1 = torch.randn(N, device=gpu_device, requires_grad=True)
+    w2 = (torch.randn(4, N, 3, 3, device=gpu_device) / (N * 9) ** 0.5).requires_grad_(True)
+    b2 = torch.randn(4, device=gpu_device, requires_grad=True)
+
+    def penalty(f, x, w1, b1, w2, b2, ctx):
+        out = f(f(x, w1, b1), w2, b2)
+        val = out.pow(2).sum(dim=(1, 2, 3))
+        with ctx():
+            gr, = torch.autograd.grad(val, x, torch.ones_like(val), create_graph=True)
+        return out, ((gr.reshape(B, -1).norm(2, dim=1) - 1) ** 2).mean() + val.mean()
+
+    import contextlib
+    out, ours = penalty(lambda a, w, b: conv2d_lrelu(a, w, b, 0.2), x, w1, b1, w2, b2, input_grads_only)
+    g_ours = torch.autograd.grad(ours, (x, w1, b1, w2, b2))
+    dd = [t.detach().double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    ref_out, ref = penalty(lambda a, w, b: F.leaky_relu(F.conv2d(a, w, b, padding=1), 0.2), *dd, contextlib.nullcontext)
+    g_ref = torch.autograd.grad(ref, dd)
+    assert relmax(out.detach().cpu().numpy(), ref_out.detach().cpu().numpy()) <= 2e-6
+    assert abs(float(ours) - float(ref)) <= 1e-5 * max(1.0, abs(float(ref)))
+    for a, b in zip(g_ours, g_ref):
+        assert relmax(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
