@@ -64,9 +64,13 @@ def _check_args(x, w, stride):
 # model and only change through DiffGrad.step / ema_update / load_state_dict -- the first two update through
 # raw pointers (no version counter moves) and therefore call `weights_changed()`.  Everything else (plain
 # torch users, the temporaries of a double backward) is packed on every call.
-_cacheable = set()
+_cacheable = {}      # (data_ptr, shape) of a registered weight -> owner (base address of the flat buffer it lives in)
 _cache = {}
-_generation = 0
+_owner_gen = {}      # owner -> generation counter, bumped when that buffer's weights change
+
+
+def _owner_of(t):
+    return t.untyped_storage().data_ptr()
 
 
 def enable_pack_cache(params=None):
@@ -75,26 +79,54 @@ def enable_pack_cache(params=None):
     _cacheable.clear()
     for p in (params or ()):
         if p.dim() == 4:
-            _cacheable.add((p.data_ptr(), tuple(p.shape)))
+            _cacheable[(p.data_ptr(), tuple(p.shape))] = _owner_of(p)
 
 
-def weights_changed():
-    """Invalidate every cached packed weight (called by the fused optimizer / EMA kernels)."""
-    global _generation
-    _generation += 1
+def weights_changed(flat=None):
+    """Invalidate the cached derived tensors (packed operands, squared-weight sums) of the weights living in the flat
+    buffer `flat` (a tensor) -- or of all registered weights.  Called by the fused optimizer / EMA kernels, which
+    update parameters through raw pointers (no version counter moves)."""
+    if flat is None:
+        for k in list(_owner_gen):
+            _owner_gen[k] += 1
+        _owner_gen[None] = _owner_gen.get(None, 0) + 1
+    else:
+        o = _owner_of(flat)
+        _owner_gen[o] = _owner_gen.get(o, 0) + 1
+
+
+def _stamp(w, owner):
+    return (_owner_gen.get(owner, 0), _owner_gen.get(None, 0), w._version)
+
+
+def cached(w, tag, compute):
+    """compute(w) cached per registered weight and `tag` until that weight's buffer changes; uncached otherwise."""
+    key = (w.data_ptr(), tuple(w.shape))
+    owner = _cacheable.get(key)
+    if owner is None:
+        return compute(w)
+    hit = _cache.get((key, tag))
+    st = _stamp(w, owner)
+    if hit is not None and hit[0] == st:
+        return hit[1]
+    val = compute(w)
+    _cache[(key, tag)] = (st, val)
+    return val
 
 
 def pack_weights(w, mode):
     """(Co,Ci,k,k) -> the packed operand Wt[k*k][Kp][Np] of hg_conv2d_fwd / hg_conv2d_dgrad."""
     key = (w.data_ptr(), tuple(w.shape))
-    if key in _cacheable:
+    owner = _cacheable.get(key)
+    if owner is not None:
         hit = _cache.get((key, mode))
-        if hit is not None and hit[0] == (_generation, w._version):
+        st = _stamp(w, owner)
+        if hit is not None and hit[0] == st:
             return hit[1]
         # a registered (training) weight needs both operands once per optimizer step: one read, two writes
         both = _pack_both(w)
         for m in (PACK_FWD, PACK_DGRAD):
-            _cache[(key, m)] = ((_generation, w._version), both[m])
+            _cache[(key, m)] = (st, both[m])
         return both[mode]
     return _pack_weights(w, mode)
 

@@ -62,6 +62,8 @@ class Conv2DMod(nn.Module):
 
     def demod_coeff(self, y):
         """d[b,o] = rsqrt(sum_{i,k} (W[o,i,k] (y[b,i]+1))^2 + EPS)   (reference :427-429)."""
+        if self.weight.is_cuda:
+            return ops.demod_coeff(y, self.weight)
         wsq = self.weight.pow(2).sum(dim=(2, 3))
         return torch.rsqrt(torch.mm((y + 1).pow(2), wsq.t()) + EPS)
 

@@ -104,7 +104,7 @@ class DiffGrad:
                                        self.exp_avg_sq.data_ptr(), self.previous_grad.data_ptr(), f.numel,
                                        float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
                                        self.step_count, _st(f.data)), 'hg_diffgrad_step')
-        weights_changed()
+        weights_changed(f.data)
 
 
 def ema_update(ma_flat, cur_flat, beta):
@@ -114,3 +114,4 @@ def ema_update(ma_flat, cur_flat, beta):
     with torch.cuda.device(ma_flat.data.device):
         check(lib.hg_ema_update(ma_flat.data.data_ptr(), cur_flat.data.data_ptr(), ma_flat.numel, float(beta),
                                 _st(ma_flat.data)), 'hg_ema_update')
+    weights_changed(ma_flat.data)
