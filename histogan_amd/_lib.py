@@ -90,6 +90,12 @@ def _load():
     lib.hg_conv2d_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32]
     lib.hg_conv2d_dgrad.restype = ctypes.c_int
     lib.hg_conv2d_dgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]
+    lib.hg_conv_b6_packed_bytes.restype = sz
+    lib.hg_conv_b6_packed_bytes.argtypes = [i32, i32, i32]
+    lib.hg_conv_b6_pack_weights.restype = ctypes.c_int
+    lib.hg_conv_b6_pack_weights.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.hg_conv2d_b6.restype = ctypes.c_int
+    lib.hg_conv2d_b6.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.hg_conv2d_wgrad_workspace_bytes.restype = sz
     lib.hg_conv2d_wgrad_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32]
     lib.hg_conv2d_wgrad.restype = ctypes.c_int
@@ -106,7 +112,7 @@ EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg
            'hg_diffgrad_step', 'hg_ema_update', 'hg_nets_workspace_bytes', 'hg_channel_sum',
            'hg_conv_packed_elems', 'hg_conv_pack_weights', 'hg_conv_pack_weights_both', 'hg_conv2d_fwd', 'hg_modconv2d_fwd', 'hg_conv2d_workspace_bytes', 'hg_conv2d_dgrad',
            'hg_conv2d_wgrad_workspace_bytes',
-           'hg_conv2d_wgrad')
+           'hg_conv2d_wgrad', 'hg_conv_b6_packed_bytes', 'hg_conv_b6_pack_weights', 'hg_conv2d_b6')
 
 
 class HgError(RuntimeError):

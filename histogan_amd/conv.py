@@ -19,6 +19,18 @@ from ._lib import check, lib
 PACK_FWD, PACK_DGRAD = 0, 1
 _skip_wgrad = False
 
+# Precision plan of the 3x3 stride-1 output / data-gradient convolutions:
+#   'f32'   v_mfma_f32_32x32x2_f32 (k_conv)            -- default
+#   'b6'    three-way bf16 split, six bf16 MFMAs per fp32 product sum (k_conv_b6): fp32-level accuracy at 2.7x the
+#           fp32-MFMA ceiling.  Used for layers with >= 16 input channels and >= B6_MIN_PIX output pixels.
+import os as _os
+PRECISION = _os.environ.get('HG_CONV_PRECISION', 'f32')
+B6_MIN_PIX = 4096
+
+
+def _use_b6(K, N, H, W, B, k, stride):
+    return PRECISION == 'b6' and k == 3 and stride == 1 and K >= 16 and B * H * W >= B6_MIN_PIX
+
 
 @contextlib.contextmanager
 def input_grads_only():
@@ -131,6 +143,26 @@ def pack_weights(w, mode):
     return _pack_weights(w, mode)
 
 
+def pack_b6(w, mode):
+    """(Co,Ci,3,3) -> the split-bf16 operand of hg_conv2d_b6 (cached like pack_weights for registered weights)."""
+    def make(t):
+        Co, Ci = t.shape[0], t.shape[1]
+        nbytes = lib.hg_conv_b6_packed_bytes(Co, Ci, mode)
+        with torch.cuda.device(t.device):
+            wt = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
+            check(lib.hg_conv_b6_pack_weights(t.data_ptr(), wt.data_ptr(), Co, Ci, mode, _st(t)), 'hg_conv_b6_pack_weights')
+        return wt
+    return cached(w, ('b6', mode), make)
+
+
+def conv_b6(x, wt, N, bias=None):
+    B, K, H, W = x.shape
+    with torch.cuda.device(x.device):
+        out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
+        check(lib.hg_conv2d_b6(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(bias), B, K, N, H, W, _st(x)), 'hg_conv2d_b6')
+    return out
+
+
 def _pack_both(w):
     Co, Ci, k, _ = w.shape
     with torch.cuda.device(w.device):
@@ -200,8 +232,10 @@ class _Conv(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.has_bias = stride, bias is not None
         xc, wc = _f32c(x), _f32c(w)
-        return conv_fwd_packed(xc, pack_weights(wc, PACK_FWD), w.shape[0], w.shape[2], stride,
-                               bias=None if bias is None else _f32c(bias))
+        bc = None if bias is None else _f32c(bias)
+        if _use_b6(xc.shape[1], w.shape[0], xc.shape[2], xc.shape[3], xc.shape[0], w.shape[2], stride):
+            return conv_b6(xc, pack_b6(wc, PACK_FWD), w.shape[0], bc)
+        return conv_fwd_packed(xc, pack_weights(wc, PACK_FWD), w.shape[0], w.shape[2], stride, bias=bc)
 
     @staticmethod
     def backward(ctx, g):
@@ -229,7 +263,10 @@ class _ConvDgrad(torch.autograd.Function):
         _check_args(g, w, stride)
         ctx.save_for_backward(g, w)
         ctx.stride = stride
-        return conv_dgrad_packed(_f32c(g), pack_weights(_f32c(w), PACK_DGRAD), w.shape[1], H, W, w.shape[2], stride)
+        gc, wc = _f32c(g), _f32c(w)
+        if _use_b6(w.shape[0], w.shape[1], H, W, gc.shape[0], w.shape[2], stride):
+            return conv_b6(gc, pack_b6(wc, PACK_DGRAD), w.shape[1])
+        return conv_dgrad_packed(gc, pack_weights(wc, PACK_DGRAD), w.shape[1], H, W, w.shape[2], stride)
 
     @staticmethod
     def backward(ctx, ggx):
