@@ -359,6 +359,8 @@ struct WgradArgs {
   float *gw;  // non-NULL: a single slab would be written -> store straight into gw (N,K,taps) instead
 };
 
+constexpr int WG_TP = 32 * 9 + 4;   // LDS row pitch of the single-slab store transpose (k_wgrad)
+
 // compile-time pixel-chunk geometry of the weight-gradient kernel: PC (output) pixels = NI images x TH x TW
 template <int PC, int LTW, int PAD, int IS>
 struct CGeom {
@@ -553,6 +555,31 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
   }
 
   if (a.gw != nullptr) {  // WS == 1 and one split: this block's tile IS the result
+    if constexpr (WS == 1 && MT == 32 && TAPS == 9) {
+      if ((K & 3) == 0) {
+        // The (n, k, tap) layout makes a wave's 32n x 32k x 9 tile 32 contiguous 1152-byte runs: transpose it through
+        // LDS and store 16-byte pieces (the direct store below writes 4-byte pieces at a 36-byte stride: 0.5 TB/s on
+        // the 151 MB gradient of a 2048x2048x3x3 layer).  The launch reserved 4 x 32 x WG_TP floats for this.
+        __syncthreads();   // operand buffers are dead
+        float *T = smem + wave * 32 * WG_TP;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int r = 0; r < M::NR; ++r) T[M::row(r, lk) * WG_TP + lm * 9 + t] = acc[t][r];
+        __syncthreads();
+        const int kbase = k0 + wk * 32;
+        const int nk = K - kbase < 32 ? K - kbase : 32;          // valid k's (multiple of 4)
+        const int nf4 = nk > 0 ? nk * 9 / 4 : 0;                 // 16-byte pieces per row
+        for (int row = 0; row < 32; ++row) {
+          const int n = n0 + wn * 32 + row;
+          if (n >= N) break;
+          float *dst = a.gw + ((size_t)n * K + kbase) * 9;
+          for (int f = lane; f < nf4; f += 64)
+            *reinterpret_cast<f32x4 *>(dst + 4 * f) = *reinterpret_cast<const f32x4 *>(T + row * WG_TP + 4 * f);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -575,6 +602,7 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
     }
 }
 
+// row pitch (floats) of the LDS transpose of a wave's 32 x (32 k x 9 taps) tile: multiple of 4 (16-byte rows)
 // gw[n][k][t] = sum_s slab[s][t][n][k].  One block per (n, tap, 32 k's): 32 lanes along k x 8 groups of
 // splits, fixed-order combine through LDS (deterministic).
 template <int TAPS>
@@ -872,6 +900,10 @@ int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
   using G = CGeom<PC, LTW, TAPS == 9 ? 1 : 0, IS>;
   size_t lds = ((size_t)WN * MT * (PC + 1) + (size_t)WK * MT * G::CHS) * sizeof(float);
   if (WS == 1 && 2 * lds <= 160 * 1024) lds *= 2;   // double buffered (NBUF in k_wgrad)
+  if (a.gw != nullptr && WS == 1 && MT == 32 && TAPS == 9) {   // room for the store transpose of the single-slab case
+    const size_t need = (size_t)WN * WK * 32 * WG_TP * sizeof(float);
+    if (need > lds) lds = need;
+  }
   auto kern = k_wgrad<WN, WK, WS, TAPS, PC, LTW, IS, MT>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -18,6 +18,8 @@ CASES = [
     # <= 16 output channels on wide maps: the 16x16x4 MFMA tile (first discriminator block, to-RGB)
     (2, 3, 16, 64, 64, 3), (2, 16, 16, 64, 64, 3), (3, 16, 3, 32, 32, 3), (2, 40, 3, 32, 32, 1), (1, 16, 16, 20, 44, 3),
     (2, 7, 12, 16, 16, 3), (2, 16, 16, 8, 8, 3),
+    # one pixel chunk, 4-wave tiles: the weight gradient is a single slab (LDS-transposed direct store; K % 4 != 0 falls back)
+    (1, 64, 64, 8, 8, 3), (1, 68, 100, 8, 8, 3), (1, 66, 70, 8, 8, 3), (2, 128, 96, 4, 4, 3),
 ]
 
 
