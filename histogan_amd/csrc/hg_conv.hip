@@ -29,6 +29,9 @@
 #ifndef HG_CONV_MINW
 #define HG_CONV_MINW 2   // __launch_bounds__ minimum waves per SIMD of k_conv (register budget 512 / MINW)
 #endif
+#ifndef HG_CONV_OPIPE
+#define HG_CONV_OPIPE 1  // explicit one-step-ahead operand pipeline in the MFMA loop of k_conv (+2.5 % on the generator layers)
+#endif
 #ifndef HG_CONV_KC
 #define HG_CONV_KC 4     // input channels per K chunk of the stride-1 tiles (64x64 tile: twice that); 2/4/8 measure within 3 %
 #endif
@@ -235,6 +238,29 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
     if (c + 1 < nchunks) prefetch(c + 1);
     if (c < c_begin) continue;
 
+#if HG_CONV_OPIPE
+    // operand reads one MFMA step ahead (explicit two-slot pipeline): the ds_reads of step s+1 are issued before the
+    // MFMAs of step s, so a wave never waits a full LDS latency between two MFMA groups
+    constexpr int NS = TAPS * (KC / KS);
+    float av[2][TC], bv[2][TP];
+    auto ldop = [&](int s_, int slot) __attribute__((always_inline)) {
+      const int t = s_ / (KC / KS), kk = s_ % (KC / KS);
+      const int toff = a.toff[t];
+#pragma unroll
+      for (int i = 0; i < TC; ++i) av[slot][i] = Ws[(t * KC + kk * KS) * NB + aoff + i * MT];
+#pragma unroll
+      for (int j = 0; j < TP; ++j) bv[slot][j] = Xs[pixoff[j] + toff + kk * KS * g.CHS];
+    };
+    ldop(0, 0);
+#pragma unroll
+    for (int s_ = 0; s_ < NS; ++s_) {
+      if (s_ + 1 < NS) ldop(s_ + 1, (s_ + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) acc[i][j] = M::mma(av[s_ & 1][i], bv[s_ & 1][j], acc[i][j]);
+    }
+#else
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
       const int toff = a.toff[t];
@@ -251,6 +277,7 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
           for (int j = 0; j < TP; ++j) acc[i][j] = M::mma(av[i], bv[j], acc[i][j]);
       }
     }
+#endif
   }
 
   // ---- epilogue: D[i = channel][j = pixel]; 32x32: row(i) = (r&3) + 8*(r>>2) + 4*(lane>>5), col(j) = lane&31;
