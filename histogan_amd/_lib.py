@@ -100,19 +100,32 @@ def _load():
     lib.hg_conv2d_wgrad_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32]
     lib.hg_conv2d_wgrad.restype = ctypes.c_int
     lib.hg_conv2d_wgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]
+    # include/hg_recolor.h
+    lib.hg_instnorm_workspace_bytes.restype = sz
+    lib.hg_instnorm_workspace_bytes.argtypes = [i64]
+    lib.hg_instnorm_lrelu_fwd.restype = ctypes.c_int
+    lib.hg_instnorm_lrelu_fwd.argtypes = [vp, vp, vp, i64, i32, f32, f32, vp, sz, vp]
+    lib.hg_instnorm_lrelu_bwd.restype = ctypes.c_int
+    lib.hg_instnorm_lrelu_bwd.argtypes = [vp, vp, vp, vp, i64, i32, f32, vp, sz, vp]
+    lib.hg_stencil3.restype = ctypes.c_int
+    lib.hg_stencil3.argtypes = [vp, vp, ctypes.POINTER(f32), i32, i32, i32, i32, i32, vp]
+    lib.hg_depthwise_valid.restype = ctypes.c_int
+    lib.hg_depthwise_valid.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp]
     return lib
 
 
 lib = _load()
 
-# every symbol include/hg_hist.h, hg_nets.h and hg_conv.h declare
+# every symbol include/hg_hist.h, hg_nets.h, hg_conv.h and hg_recolor.h declare
 EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_fwd',
            'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd',
            'hg_modulate_fwd', 'hg_modulate_bwd', 'hg_demod_noise_lrelu_fwd', 'hg_demod_noise_lrelu_bwd',
            'hg_diffgrad_step', 'hg_ema_update', 'hg_nets_workspace_bytes', 'hg_channel_sum',
            'hg_conv_packed_elems', 'hg_conv_pack_weights', 'hg_conv_pack_weights_both', 'hg_conv2d_fwd', 'hg_modconv2d_fwd', 'hg_conv2d_workspace_bytes', 'hg_conv2d_dgrad',
            'hg_conv2d_wgrad_workspace_bytes',
-           'hg_conv2d_wgrad', 'hg_conv_b6_packed_bytes', 'hg_conv_b6_pack_weights', 'hg_conv2d_b6')
+           'hg_conv2d_wgrad', 'hg_conv_b6_packed_bytes', 'hg_conv_b6_pack_weights', 'hg_conv2d_b6',
+           'hg_instnorm_workspace_bytes', 'hg_instnorm_lrelu_fwd', 'hg_instnorm_lrelu_bwd', 'hg_stencil3',
+           'hg_depthwise_valid')
 
 
 class HgError(RuntimeError):

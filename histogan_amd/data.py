@@ -28,7 +28,8 @@ def _load_rgb(path, size=None):
 
 
 class FolderData:
-    def __init__(self, folder, hist_block, batch_size, image_size, device, transparent=False, seed=0, test=False):
+    def __init__(self, folder, hist_block, batch_size, image_size, device, transparent=False, seed=0, test=False,
+                 hist_sampling=True):
         if transparent:
             raise NotImplementedError('transparent (RGBA) images are not supported')
         self.paths = [p for ext in EXTS for p in Path(f'{folder}').glob(f'**/*.{ext}')]
@@ -36,6 +37,9 @@ class FolderData:
             raise FileNotFoundError(f'no {EXTS} images under {folder}')
         self.hist_block, self.B, self.S, self.device, self.test = hist_block, batch_size, image_size, device, test
         self.rs = np.random.RandomState(seed)
+        # True: target = interpolation of the histograms of two OTHER random images; False: the image's own
+        # histogram (ReHistoGAN/rehistoGAN.py:375-446, `hist_sampling`)
+        self.hist_sampling = hist_sampling
 
     def _hist_of(self, idx):
         # full-resolution images differ in size: one GPU call per image, still no CPU histogram
@@ -55,6 +59,8 @@ class FolderData:
             return {'histograms': self._hist_of(self.rs.randint(0, n, self.B))}
         idx = self.rs.randint(0, n, self.B)
         images = torch.stack([_load_rgb(self.paths[i], self.S) for i in idx]).to(self.device)
+        if not self.hist_sampling:
+            return {'images': images, 'histograms': self._hist_of(idx)}
         h1 = self._hist_of(self.rs.randint(0, n, self.B))
         h2 = self._hist_of(self.rs.randint(0, n, self.B))
         ratio = torch.rand(self.B, 1, 1, 1, device=self.device)   # hist_interpolation (:180-182), per item

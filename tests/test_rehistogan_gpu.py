@@ -1,0 +1,255 @@
+"""ReHistoGAN pieces on the GPU: the hg_recolor.h kernels against torch fp64, the
+encoder-decoder / recolouring head / losses against the goldens of the reference classes, one train step against
+the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN_DIR, relmax
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = dict(plain=(False, False), skip=(True, False), skipint=(True, True))
+
+
+@pytest.fixture(scope='module')
+def g():
+    z = np.load(os.path.join(GOLDEN_DIR, 'rehistogan_small.npz'))
+    return {k: z[k] for k in z.files}
+
+
+def T(a, dev, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.requires_grad_(True) if grad else t
+
+
+def sd_of(g, prefix, dev):
+    return {k[len(prefix) + 1:]: T(v, dev) for k, v in g.items() if k.startswith(prefix + '/')}
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 8, 8), (1, 2, 256, 256), (3, 5, 7, 9), (2, 40, 16, 16), (1, 1, 1, 2),
+                                   (4, 16, 64, 64)])
+def test_instnorm_lrelu_matches_torch(shape, gpu_device):
+    from histogan_amd import reops
+    torch.manual_seed(sum(shape))
+    x = (torch.randn(shape) * 3 + 5).to(gpu_device).requires_grad_(True)      # mean >> 0: cancellation-prone
+    go = torch.randn(shape).to(gpu_device)
+    y = reops.instnorm_lrelu(x)
+    gx, = torch.autograd.grad(y, x, go)
+    xd = x.detach().double().requires_grad_(True)
+    yd = F.leaky_relu(F.instance_norm(xd, eps=1e-5), 0.2)
+    gd, = torch.autograd.grad(yd, xd, go.double())
+    assert relmax(y.detach().cpu().numpy(), yd.detach().cpu().numpy()) <= 2e-6
+    # gx = rstd * (m - mean(m) - xhat * mean(m * xhat)): a difference of terms of size |go| * rstd
+    rstd = 1.0 / torch.sqrt(xd.detach().var(dim=(2, 3), unbiased=False, keepdim=True) + 1e-5)
+    scale = float((go.double().abs() * rstd).max())
+    assert float((gx.double() - gd).abs().max()) <= 2e-5 * scale
+    # same bits on a second run (fixed-order partial sums)
+    assert torch.equal(reops.instnorm_lrelu(x.detach()), y.detach())
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 40, 40), (1, 3, 5, 70), (3, 1, 1, 1), (2, 4, 33, 17)])
+def test_stencil3_matches_torch(shape, gpu_device):
+    from histogan_amd import reops
+    torch.manual_seed(1)
+    taps = torch.randn(3, 3)
+    x = torch.randn(shape).to(gpu_device).requires_grad_(True)
+    y = reops.stencil3(x, taps)
+    go = torch.randn_like(y).requires_grad_(True)
+    gx, = torch.autograd.grad(y, x, go, create_graph=True)
+    xd = x.detach().double().requires_grad_(True)
+    k = taps.double().to(gpu_device)[None, None].expand(1, shape[1], 3, 3)
+    yd = F.conv2d(xd, k, padding=1)
+    gd, = torch.autograd.grad(yd, xd, go.detach().double())
+    assert y.shape == yd.shape
+    assert relmax(y.detach().cpu().numpy(), yd.detach().cpu().numpy()) <= 1e-6
+    assert relmax(gx.detach().cpu().numpy(), gd.cpu().numpy()) <= 1e-6
+    # linear => the backward is differentiable again: d sum(adjoint(go)) / d go = stencil(ones)
+    g2, = torch.autograd.grad(gx.sum(), go)
+    ref2 = F.conv2d(torch.ones(shape, dtype=torch.float64, device=gpu_device), k, padding=1)
+    assert relmax(g2.cpu().numpy(), ref2.cpu().numpy()) <= 1e-6
+
+
+@pytest.mark.parametrize('shape,ks', [((2, 3, 40, 40), 15), ((1, 3, 64, 50), 15), ((1, 2, 15, 15), 15),
+                                      ((2, 3, 70, 33), 5)])
+def test_gaussian_valid_matches_torch(shape, ks, gpu_device):
+    from histogan_amd import reops
+    torch.manual_seed(2)
+    k2 = torch.rand(ks, ks)
+    k2 = (k2 / k2.sum()).to(gpu_device)            # NOT symmetric: checks the flip of the adjoint
+    x = torch.randn(shape).to(gpu_device).requires_grad_(True)
+    y = reops.gaussian_valid(x, k2)
+    go = torch.randn_like(y)
+    gx, = torch.autograd.grad(y, x, go)
+    xd = x.detach().double().requires_grad_(True)
+    yd = F.conv2d(xd, k2.double()[None, None].repeat(shape[1], 1, 1, 1), groups=shape[1])
+    gd, = torch.autograd.grad(yd, xd, go.double())
+    assert y.shape == yd.shape
+    assert relmax(y.detach().cpu().numpy(), yd.detach().cpu().numpy()) <= 1e-6
+    assert relmax(gx.cpu().numpy(), gd.cpu().numpy()) <= 1e-6
+
+
+def _build(g, tag, dev):
+    from ReHistoGAN.rehistoGAN import RecoloringEncoderDecoder, RecoloringGAN
+    skip, internal = VARIANTS[tag]
+    S_, CAP, LAT, HB, B = [int(v) for v in g['meta']]
+    ED = RecoloringEncoderDecoder(S_, network_capacity=CAP, hist=HB, latent_dim=LAT, style_depth=3,
+                                  skip_conn_to_GAN=skip, internal_hist=internal).to(dev)
+    G = RecoloringGAN(S_, LAT, CAP).to(dev)
+    ED.load_state_dict(sd_of(g, f'{tag}/ED', dev))
+    G.load_state_dict(sd_of(g, f'{tag}/G', dev))
+    return ED, G
+
+
+@pytest.mark.parametrize('tag', list(VARIANTS))
+def test_encoder_decoder_and_head_golden(g, tag, gpu_device):
+    skip, internal = VARIANTS[tag]
+    ED, G = _build(g, tag, gpu_device)
+    x = T(g['img'], gpu_device, True)
+    hw = T(g['hw'], gpu_device)
+    res = ED(x, hw if internal else T(g['hist'], gpu_device))
+    gen = G(res[0], res[1], hw, T(g['noise'], gpu_device), *(res[2:] if skip else ()))
+    assert relmax(res[0].detach().cpu().numpy(), g[f'{tag}/latent']) <= 2e-5
+    assert relmax(res[1].detach().cpu().numpy(), g[f'{tag}/rgb']) <= 2e-5
+    if skip:
+        assert relmax(res[2].detach().cpu().numpy(), g[f'{tag}/p1']) <= 2e-5
+        assert relmax(res[3].detach().cpu().numpy(), g[f'{tag}/p2']) <= 2e-5
+    assert relmax(gen.detach().cpu().numpy(), g[f'{tag}/gen']) <= 2e-5
+    en = [k[len(f'{tag}/ed_grad/'):] for k in g if k.startswith(f'{tag}/ed_grad/')]
+    gn = [k[len(f'{tag}/g_grad/'):] for k in g if k.startswith(f'{tag}/g_grad/')]
+    ep, gp = dict(ED.named_parameters()), dict(G.named_parameters())
+    grads = torch.autograd.grad(gen, [x] + [ep[n] for n in en] + [gp[n] for n in gn], T(g[f'{tag}/go'], gpu_device))
+    assert relmax(grads[0].cpu().numpy(), g[f'{tag}/gx']) <= 2e-4
+    for n, gr in zip(en, grads[1:1 + len(en)]):
+        ref = g[f'{tag}/ed_grad/{n}']
+        if n.endswith('net.3.bias') or n.endswith('net.0.bias'):
+            continue    # a bias in front of an instance norm has zero gradient; the reference's value is rounding noise
+        assert relmax(gr.cpu().numpy(), ref) <= 2e-4, n
+    for n, gr in zip(gn, grads[1 + len(en):]):
+        assert relmax(gr.cpu().numpy(), g[f'{tag}/g_grad/{n}']) <= 2e-4, n
+
+
+@pytest.mark.parametrize('kind,tag', [('L1', 'l1'), ('1st gradient', 'sobel'), ('2nd gradient', 'lap')])
+def test_reconstruction_loss_golden(g, kind, tag, gpu_device):
+    from ReHistoGAN.rehistoGAN import reconstruction_loss
+    a, b = T(g['loss_a'], gpu_device), T(g['loss_b'], gpu_device, True)
+    v = reconstruction_loss(kind).compute_loss(a, b)
+    assert abs(float(v) - float(g[f'rec_{tag}'])) <= 2e-6 * max(1.0, abs(float(g[f'rec_{tag}'])))
+    gr, = torch.autograd.grad(v, b)
+    assert relmax(gr.cpu().numpy(), g[f'rec_{tag}_grad']) <= 1e-5
+
+
+def test_gaussian_and_variance_loss_golden(g, gpu_device):
+    from ReHistoGAN.rehistoGAN import gaussian_op, get_gaussian_kernel
+    k = get_gaussian_kernel(15, 5, 3)
+    assert np.array_equal(k.numpy(), g['gauss_k'])
+    k = k.to(gpu_device)
+    a, b = T(g['loss_a'], gpu_device), T(g['loss_b'], gpu_device, True)
+    assert relmax(gaussian_op(a, k).cpu().numpy(), g['gauss_out']) <= 1e-6
+    hist, h2 = T(g['hist'], gpu_device), T(g['hist2'], gpu_device)
+    v = -1 * (1.5 / 10) * torch.sum(torch.abs(hist - h2)) * torch.mean(torch.abs(
+        torch.std(torch.std(gaussian_op(a, k), dim=2), dim=2) - torch.std(torch.std(gaussian_op(b, k), dim=2), dim=2)))
+    assert abs(float(v) - float(g['var_loss'])) <= 1e-5 * max(1.0, abs(float(g['var_loss'])))
+    gr, = torch.autograd.grad(v, b)
+    assert relmax(gr.cpu().numpy(), g['var_grad']) <= 1e-4
+
+
+class _NoiseReplay:
+    def __init__(self, dev, B, S, seed):
+        gen = torch.Generator().manual_seed(seed)
+        self.dev, self.n, self.i = dev, [torch.rand(B, S, S, 1, generator=gen) for _ in range(2)], 0
+
+    def image_noise(self, n, s):
+        x = self.n[self.i]; self.i += 1
+        return x.to(self.dev)
+
+
+@pytest.mark.parametrize('skip,internal,rec', [(True, False, 'laplacian'), (False, True, 'sobel')])
+def test_train_step_matches_oracle(skip, internal, rec, gpu_device, tmp_path):
+    """One recoloringTrainer.train() step at step 0 (gradient penalty active, variance loss on) against the same
+    step evaluated with oracle/ (functional nets + oracle histogram) on CPU: losses and generator-side gradients."""
+    from ReHistoGAN import recoloringTrainer
+    from oracle import histogan_nets as N
+    from oracle import rehistogan_nets as RN
+    from oracle import rgbuv_hist as OH
+    torch.manual_seed(3)
+    S_, CAP, B, HB, LR = 64, 2, 2, 16, 2e-4
+    ALPHA, BETA, GAMMA = 32, 1.5, 4
+    tr = recoloringTrainer('r', tmp_path / 'r', tmp_path / 'm', S_, CAP, batch_size=B, lr=LR, hist_bin=HB,
+                           hist_insz=150, hist_resizing='interpolation', skip_conn_to_GAN=skip,
+                           internal_hist=internal, rec_loss=rec, variance_loss=True)
+    tr.run_evaluate = tr.run_save = False
+    tr.init_GAN()
+    GAN = tr.GAN
+    with torch.no_grad():
+        for blk in GAN.G.blocks:
+            blk.to_noise1.weight.normal_(std=0.3); blk.to_noise2.weight.normal_(std=0.3)
+    sd0 = {k: v.detach().cpu().clone() for k, v in GAN.state_dict().items()}
+    gen = torch.Generator().manual_seed(5)
+    batches = []
+    for _ in range(2):
+        img = torch.rand(B, 3, S_, S_, generator=gen)
+        hist = OH.rgbuv_hist(torch.rand(B, 3, S_, S_, generator=gen), h=HB)
+        batches.append({'images': img, 'histograms': hist})
+    tr.loader = iter([{k: v.to(gpu_device) for k, v in b.items()} for b in batches])
+    tr.rng = _NoiseReplay(gpu_device, B, S_, 9)
+    tr.train(alpha=ALPHA, beta=BETA, gamma=GAMMA)
+
+    rc = _NoiseReplay(torch.device('cpu'), B, S_, 9)
+    sub = lambda p: {k[len(p) + 1:]: sd0[k].clone().requires_grad_(True) for k in sd0 if k.startswith(p + '.')}
+    sE, sG, sH, sD = sub('ED'), sub('G'), sub('H'), sub('D')
+    nblk = int(np.log2(S_))
+
+    def recolor(img, hist, noise):
+        hw = N.vectorizer(sH, hist, 'fcs')
+        res = RN.encoder_decoder(sE, img, hw if internal else hist, S_, skip, internal)
+        return RN.recoloring_head(sG, res[0], hw, noise, *(res[2:] if skip else ()))
+
+    # D phase
+    noise = rc.image_noise(B, S_)
+    img = batches[0]['images'].clone().requires_grad_(True)
+    with torch.no_grad():
+        fake = recolor(img, batches[0]['histograms'], noise)
+    real_out, fake_out = N.discriminator(sD, img, nblk), N.discriminator(sD, fake, nblk)
+    div = (F.relu(1 + real_out) + F.relu(1 - fake_out)).mean()
+    d_loss = div + N.gradient_penalty(img, real_out)
+    dk = list(sD.keys())
+    for k, gr in zip(dk, torch.autograd.grad(d_loss, [sD[k] for k in dk])):
+        st = dict(step=0, exp_avg=torch.zeros_like(gr), exp_avg_sq=torch.zeros_like(gr), previous_grad=torch.zeros_like(gr))
+        with torch.no_grad():
+            N.diffgrad_step(sD[k], gr, st, lr=LR, betas=(0.5, 0.9))
+    # G phase (updated discriminator)
+    noise = rc.image_noise(B, S_)
+    img, hist = batches[1]['images'], batches[1]['histograms']
+    out = recolor(img, hist, noise)
+    adv = GAMMA * N.discriminator(sD, out, nblk).mean()
+    h_loss = OH.hellinger_loss(hist, OH.rgbuv_hist(F.relu(out), h=HB), ALPHA)
+    r_loss = BETA * RN.rec_loss({'laplacian': '2nd gradient', 'sobel': '1st gradient'}[rec], img, out)
+    v_loss = RN.variance_loss(BETA, hist, OH.rgbuv_hist(F.relu(hist), h=HB), img, out, RN.gaussian_kernel(15, 5, 3))
+    g_loss = adv + h_loss + r_loss + v_loss
+    groups = [('ED', sE), ('G', sG), ('H', sH)]
+    keys = [(p, k) for p, s in groups for k in s]
+    ggr = torch.autograd.grad(g_loss, [dict(groups)[p][k] for p, k in keys], allow_unused=True)
+
+    assert abs(tr.d_loss - float(div)) <= 1e-4 * max(1.0, abs(float(div)))
+    assert abs(tr.g_loss - float(adv)) <= 1e-4 * max(1.0, abs(float(adv)))
+    assert abs(tr.h_loss - float(h_loss)) <= 2e-4 * max(1.0, abs(float(h_loss)))
+    assert abs(tr.r_loss - float(r_loss)) <= 1e-4 * max(1.0, abs(float(r_loss)))
+    assert abs(tr.var_loss - float(v_loss)) <= 1e-4 * max(1.0, abs(float(v_loss)))
+    worst = 0.0
+    for (p, k), gr in zip(keys, ggr):
+        mine = dict(getattr(GAN, p).named_parameters())[k].grad
+        if gr is None:                       # decoder conv_out_rgb: feeds only the rgb the head discards
+            assert mine is None or float(mine.abs().max()) == 0.0, (p, k)
+            continue
+        if p == 'ED' and ('.net.0.bias' in k or '.net.3.bias' in k):
+            continue                         # bias in front of an instance norm: exact zero vs rounding noise
+        e = relmax(mine.detach().cpu().numpy(), gr.numpy())
+        worst = max(worst, e)
+        # 1e-2: same conditioning argument as tests/test_nets_gpu.py::test_train_step_matches_oracle (d hist / d x
+        # near the clamp edge); the Sobel magnitude adds sqrt() near zero
+        assert e <= 1e-2, (p, k, e)
+    print('worst generator-side gradient error', worst)
