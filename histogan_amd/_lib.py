@@ -111,12 +111,21 @@ def _load():
     lib.hg_stencil3.argtypes = [vp, vp, ctypes.POINTER(f32), i32, i32, i32, i32, i32, vp]
     lib.hg_depthwise_valid.restype = ctypes.c_int
     lib.hg_depthwise_valid.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    # include/hg_augment.h
+    lib.hg_augment_spatial.restype = ctypes.c_int
+    lib.hg_augment_spatial.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.hg_augment_workspace_bytes.restype = sz
+    lib.hg_augment_workspace_bytes.argtypes = [i32]
+    lib.hg_sample_mean.restype = ctypes.c_int
+    lib.hg_sample_mean.argtypes = [vp, vp, i32, i64, vp, sz, vp]
+    lib.hg_augment_color.restype = ctypes.c_int
+    lib.hg_augment_color.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     return lib
 
 
 lib = _load()
 
-# every symbol include/hg_hist.h, hg_nets.h, hg_conv.h and hg_recolor.h declare
+# every symbol include/hg_hist.h, hg_nets.h, hg_conv.h, hg_recolor.h and hg_augment.h declare
 EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_fwd',
            'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd',
            'hg_modulate_fwd', 'hg_modulate_bwd', 'hg_demod_noise_lrelu_fwd', 'hg_demod_noise_lrelu_bwd',
@@ -125,7 +134,8 @@ EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg
            'hg_conv2d_wgrad_workspace_bytes',
            'hg_conv2d_wgrad', 'hg_conv_b6_packed_bytes', 'hg_conv_b6_pack_weights', 'hg_conv2d_b6',
            'hg_instnorm_workspace_bytes', 'hg_instnorm_lrelu_fwd', 'hg_instnorm_lrelu_bwd', 'hg_stencil3',
-           'hg_depthwise_valid')
+           'hg_depthwise_valid', 'hg_augment_spatial', 'hg_augment_workspace_bytes', 'hg_sample_mean',
+           'hg_augment_color')
 
 
 class HgError(RuntimeError):

@@ -28,6 +28,7 @@ from torch import nn
 from torch.autograd import grad as torch_grad
 
 from . import ddp
+from .augment import AugWrapper
 from .conv import enable_pack_cache, input_grads_only, weights_changed
 from .hist import hellinger_loss
 from .nets import Discriminator, Generator, HistVectorizer, StyleVectorizer
@@ -133,8 +134,6 @@ class HistoGAN(nn.Module):
         super().__init__()
         if fp16:
             raise NotImplementedError('fp16/apex is not offered: the MI355X path is fp32 (as the reference default)')
-        if aug:
-            raise NotImplementedError('DiffAugment (aug_prob > 0) is out of scope of the MI355X hot path')
         self.lr = lr
         self.aug = aug
         self.steps = steps
@@ -147,7 +146,8 @@ class HistoGAN(nn.Module):
         self.SE = StyleVectorizer(latent_dim, style_depth)
         self.HE = HistVectorizer(hist, latent_dim, int(style_depth))
         self.GE = Generator(image_size, latent_dim, network_capacity, transparent=transparent)
-        self.D_aug = None
+        # wrapper augmenting all images going into the discriminator (reference :658-662)
+        self.D_aug = AugWrapper(self.D) if aug else None
         set_requires_grad(self.SE, False)
         set_requires_grad(self.HE, False)
         set_requires_grad(self.GE, False)
@@ -345,6 +345,9 @@ class Trainer():
         acc = self.gradient_accumulate_every
         apply_gradient_penalty = self.steps % 4 == 0
         apply_path_penalty = self.steps % 32 == 0
+        # DiffAugment of everything the discriminator sees (reference :873-878, 905-908, 950-951)
+        aug = (lambda im, detach=False: GAN.D_aug.augment(im, prob=self.aug_prob, types=self.aug_types, detach=detach)
+               ) if self.aug_prob > 0.0 else (lambda im, detach=False: im)
 
         # ---- discriminator phase (reference :889-932)
         GAN.D_opt.zero_grad()
@@ -360,7 +363,7 @@ class Trainer():
                 generated_images = GAN.G(w_styles, h_w_space, noise)
             # one discriminator pass over [fake; real] (samples are independent: same values as two passes,
             # :911-912, but twice the pixels per launch on the small maps)
-            both_output, both_q_loss = Disc(torch.cat((generated_images, image_batch), dim=0))
+            both_output, both_q_loss = Disc(torch.cat((aug(generated_images, True), aug(image_batch)), dim=0))
             fake_output, real_output = both_output[:batch_size], both_output[batch_size:]
             fake_q_loss = real_q_loss = both_q_loss * 0.5
             divergence = (F.relu(1 + real_output) + F.relu(1 - fake_output)).mean()
@@ -393,7 +396,7 @@ class Trainer():
                 GAN._reduce_d.finish()
                 GAN.D_opt.step()
                 d_updated = True
-            fake_output, _ = Disc(generated_images)
+            fake_output, _ = Disc(aug(generated_images))
             generated_histograms = self.histBlock(F.relu(generated_images))
             histogram_loss = hellinger_loss(hist_batch, generated_histograms, alpha)
             loss = fake_output.mean()
