@@ -253,13 +253,19 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local % max(1, torch.cuda.device_count()))
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        # 'nccl' == RCCL over xGMI.  HG_DIST_BACKEND=gloo exists to exercise the N>1 path on a box with fewer GPUs than
+        # ranks (ranks then share a device; test use only)
+        backend = os.environ.get('HG_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     hstep, time_kernels, work, hinfo, units = hist_workload(args, dev, rank, world)
     if args.workload == 'train':
