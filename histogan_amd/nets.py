@@ -97,7 +97,7 @@ class RGBBlock(nn.Module):
         return self.forward_(x, prev_rgb, self.to_style(istyle))
 
     def forward_(self, x, prev_rgb, style):
-        if GeneratorBlock.FUSED and x.is_cuda and not self.conv.demod and self.conv.kernel == 1:
+        if GeneratorBlock._fused() and x.is_cuda and not self.conv.demod and self.conv.kernel == 1:
             x = ops.modconv_stage(x, style, self.conv.weight, demod=False, upsample=False, act=False)
         else:
             x = self.conv(x, style)
@@ -125,11 +125,16 @@ class GeneratorBlock(nn.Module):
     # LeakyReLU as ONE forward launch (ops.modconv_stage -> hg_modconv2d_fwd).  Measured on MI355X at the C3 shapes
     # (tools/modconv_probe.py) the fused forward saves 0.03-0.17 ms per stage but its backward needs the modulation
     # inside the weight-gradient kernel (+0.06-0.1 ms), so the train step is 1-3 % faster with the three-kernel
-    # plan below (prologue kernel, convolution, epilogue kernel); inference-only use profits from FUSED.
+    # plan below (prologue kernel, convolution, epilogue kernel).  Without autograd (the D phase's generator forward,
+    # evaluate()) there is no backward to pay for, so the fused launch is used there whatever FUSED says.
     FUSED = False
 
+    @classmethod
+    def _fused(cls):
+        return cls.FUSED or not torch.is_grad_enabled()
+
     def _stage(self, conv, x, style, nzt, to_noise, upsample):
-        if self.FUSED and conv.stride == 1 and conv.dilation == 1 and conv.kernel in (1, 3):
+        if self._fused() and conv.stride == 1 and conv.dilation == 1 and conv.kernel in (1, 3):
             return ops.modconv_stage(x, style, conv.weight, nzt, to_noise.weight, to_noise.bias,
                                      demod=conv.demod, upsample=upsample, act=True)
         c = conv.contract(x, style, upsample)

@@ -26,7 +26,8 @@ from .hist import hellinger_loss
 from .nets import Discriminator, HistVectorizer
 from .optim import DiffGrad, FlatParams
 from .renets import RecoloringEncoderDecoder, RecoloringGAN
-from .trainer import NanException, SyntheticData, _Rng, cast_list, gradient_penalty, set_requires_grad
+from .trainer import (NanException, SyntheticData, _freeze_gc_once, _Rng, cast_list, gradient_penalty,
+                      set_requires_grad)
 
 SOBEL_X = ((1, 0, -1), (2, 0, -2), (1, 0, -1))
 SOBEL_Y = ((1, 2, 1), (0, 0, 0), (-1, -2, -1))
@@ -281,6 +282,7 @@ class recoloringTrainer():
             self.init_GAN()
         GAN = self.GAN
         GAN.train()
+        _freeze_gc_once(self)
         dev = self.device
         zero = lambda: torch.zeros((), device=dev)
         total_disc_loss, total_gen_loss, total_rec_loss, total_hist_loss, total_var_loss = (zero() for _ in range(5))
