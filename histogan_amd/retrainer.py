@@ -297,7 +297,8 @@ class recoloringTrainer():
         GAN.D_opt.zero_grad()
         for i in range(acc):
             batch = next(self.loader)
-            image_batch = batch['images'].to(dev).detach().requires_grad_()
+            # d D(real) / d images is only needed by the gradient penalty (the reference sets requires_grad always, :897)
+            image_batch = batch['images'].to(dev).detach().requires_grad_(apply_gradient_penalty)
             hist_batch = batch['histograms'].to(dev)
             noise = self.rng.image_noise(batch_size, image_size)
             with torch.no_grad():       # the reference detaches this output; no graph is needed

@@ -369,7 +369,8 @@ class Trainer():
             style = get_latents_fn(batch_size, num_layers - 2, latent_dim)
             noise = self.rng.image_noise(batch_size, image_size)
             batch = next(self.loader)
-            image_batch = batch['images'].to(dev).detach().requires_grad_()
+            # d D(real) / d images is only needed by the gradient penalty (the reference sets requires_grad always, :897)
+            image_batch = batch['images'].to(dev).detach().requires_grad_(apply_gradient_penalty)
             hist_batch = batch['histograms'].to(dev)
             with torch.no_grad():   # the reference detaches this output; no graph is needed
                 w_styles, h_w_space = self._w_and_hw(style, hist_batch)

@@ -1,6 +1,7 @@
 """Not a test: prints parity errors for every golden case (debug aid, run on the GPU box)."""
 import sys, os, traceback
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
 from conftest import golden_names, load_golden, relmax
 from histogram_classes.RGBuvHistBlock import RGBuvHistBlock
