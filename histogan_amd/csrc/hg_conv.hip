@@ -33,7 +33,10 @@
 #define HG_CONV_OPIPE 1  // explicit one-step-ahead operand pipeline in the MFMA loop of k_conv (+2.5 % on the generator layers)
 #endif
 #ifndef HG_CONV_KC
-#define HG_CONV_KC 4     // input channels per K chunk of the stride-1 tiles (64x64 tile: twice that); 2/4/8 measure within 3 %
+#define HG_CONV_KC 4
+#ifndef HG_CONV_BIGTILE_SPLITK
+#define HG_CONV_BIGTILE_SPLITK 1
+#endif     // input channels per K chunk of the stride-1 tiles (64x64 tile: twice that); 2/4/8 measure within 3 %
 #endif
 
 namespace {
@@ -782,7 +785,7 @@ struct ConvPlan {
 // Pick the largest tile that still gives >= ~1.5 blocks per CU.  Wide tiles need wide rows (the staging-register
 // bound R16 in k_conv): 256-pixel tiles Wc > 8, 128-pixel tiles Wc > 4.  Launches that cannot fill the chip with
 // output tiles (few pixels, many channels: the 2x2 ... 8x8 maps) split the reduction over K into slabs.
-ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool have_ws) {
+ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool have_ws, bool big_split = true) {
   const long long pix = (long long)B * Hc * Wc;
   auto blocks = [&](int nb, int mb) { return ((N + nb - 1) / nb) * ((pix + mb - 1) / mb); };
   const bool wide256 = Wc > 8 && Hc > 8, wide128 = Wc > 4 && Hc > 4;
@@ -791,7 +794,21 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
   if (N <= 16 && wide256) { p.tile = TILE_16x256; return p; }
   if (N <= 32 && wide256) { p.tile = TILE_32x256; return p; }
   if (N <= 64 && wide256 && blocks(64, 256) >= 384) { p.tile = TILE_64x256; return p; }
-  if (N > 64 && wide128 && blocks(128, 128) >= 256) { p.tile = TILE_128x128; return p; }
+  if (N > 64 && wide128) {
+    const long long nb = blocks(128, 128);
+    if (nb >= 256) { p.tile = TILE_128x128; return p; }
+#if HG_CONV_BIGTILE_SPLITK
+    // few pixels, many channels (8x8 maps): keep the 128x128 tile (half the LDS operand reads per MFMA of the 64x64
+    // one) and get the blocks from a K split instead
+    const int nch = (K + HG_CONV_KC - 1) / HG_CONV_KC;
+    if (big_split && have_ws && os == 1 && IS == 1 && nb >= 32 && nch >= 32) {
+      int ks = (int)((512 + nb - 1) / nb);
+      if (ks > nch / 8) ks = nch / 8;
+      if (ks > 16) ks = 16;
+      if (ks > 1) { p.tile = TILE_128x128; p.ksplit = ks; return p; }
+    }
+#endif
+  }
   p.tile = TILE_64x64;
   // pixel tiles of the 64x64 shape: images are grouped when the map is smaller than the tile
   const int tw = Wc <= 2 && IS == 1 ? 2 : (Wc <= 4 ? 4 : (Wc <= 8 ? 8 : (Wc <= 16 ? 16 : 32)));
@@ -868,7 +885,7 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
       return launch_conv<1, 4, 1, 4, TAPS, 4, IS, false, 16>(a, tp, 1, true, st);
     case TILE_32x256: return launch_conv<1, 4, 1, 2, TAPS, KC, IS>(a, tp, 1, true, st);
     case TILE_64x256: return launch_conv<1, 4, 2, 2, TAPS, KC, IS>(a, tp, 1, true, st);
-    case TILE_128x128: return launch_conv<2, 2, 2, 2, TAPS, KC, IS>(a, tp, 1, true, st);
+    case TILE_128x128: return launch_conv<2, 2, 2, 2, TAPS, KC, IS>(a, tp, p.ksplit, true, st);
     default: return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, IS == 1>(a, tp, p.ksplit, true, st);
   }
 }
@@ -1018,7 +1035,7 @@ size_t hg_conv2d_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t Hi, in
   if (dgrad) {
     if (stride != 1) {
       if (Hi == 1 || Wi == 1) return 0;
-      const ConvPlan p = plan_conv(B, K, N, (Hi + 1) / 2, (Wi + 1) / 2, 1, 1, true);
+      const ConvPlan p = plan_conv(B, K, N, (Hi + 1) / 2, (Wi + 1) / 2, 1, 1, true, false);
       return p.tile == TILE_64x64 && p.ksplit > 1 ? (size_t)p.ksplit * B * N * Hi * Wi * sizeof(float) : 0;
     }
     return conv_ws_bytes(plan_conv(B, K, N, Hi, Wi, 1, 1, true), B, N, Hi, Wi);
@@ -1114,7 +1131,7 @@ int hg_conv2d_dgrad(const float *gout, const float *wt, float *gin, const float 
   // K split decided once for the four parity launches (they fill disjoint pixels of the same slabs)
   int ksplit = 0;
   {
-    ConvPlan p = plan_conv(B, K, N, (Hi + 1) / 2, (Wi + 1) / 2, 1, 1, workspace != nullptr);
+    ConvPlan p = plan_conv(B, K, N, (Hi + 1) / 2, (Wi + 1) / 2, 1, 1, workspace != nullptr, false);
     // (a 1-pixel-wide image has empty parity classes, whose slab pixels would never be written: no split then)
     if (Hi > 1 && Wi > 1 && p.tile == TILE_64x64 && p.ksplit > 1 &&
         (size_t)p.ksplit * B * N * Hi * Wi * sizeof(float) <= workspace_bytes)

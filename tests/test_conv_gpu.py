@@ -20,6 +20,8 @@ CASES = [
     (2, 7, 12, 16, 16, 3), (2, 16, 16, 8, 8, 3),
     # one pixel chunk, 4-wave tiles: the weight gradient is a single slab (LDS-transposed direct store; K % 4 != 0 falls back)
     (1, 64, 64, 8, 8, 3), (1, 68, 100, 8, 8, 3), (1, 66, 70, 8, 8, 3), (2, 128, 96, 4, 4, 3),
+    # few pixels, many channels: the 128x128 tile with a K split (forward 132->500, data gradient 500->132 ... both > 64)
+    (16, 132, 500, 8, 8, 3), (16, 256, 260, 8, 8, 3), (6, 192, 640, 12, 12, 3),
 ]
 
 
