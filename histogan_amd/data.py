@@ -1,11 +1,20 @@
-"""Minimal image-folder source and image-grid writer (PIL only; torchvision is absent in this image).
+"""Image-folder source and image-grid writer (PIL only; torchvision is absent in this image).
 
-The reference's Dataset (histoGAN/histoGAN.py:253-307) decodes with PIL/torchvision in DataLoader
-workers and computes two CPU target histograms per item; that pipeline is outside the hot-path scope
-(SURVEY.md section 8f row f-2).  This source keeps the same item contract -- {'images': (B,3,S,S) in
-[0,1], 'histograms': interpolation of the histograms of two other random images} -- but computes the
-target histograms as ONE batched GPU call per batch.
+The reference's Dataset (histoGAN/histoGAN.py:253-307, ReHistoGAN/rehistoGAN.py:335-446) decodes with PIL/torchvision in
+DataLoader workers and computes TWO CPU target histograms of full-resolution images per item (~1 s each on the
+reference's fp64 CPU path): at the 470 images/s of the GPU step that pipeline would starve the GPU by three orders of
+magnitude.  This source keeps the item contract -- {'images': (B,3,S,S) in [0,1],
+'histograms': interpolation of the histograms of two other random images, or the image's own} -- and restructures it:
+
+* decoding / resizing runs in a thread pool (PIL releases the GIL) and batches are prefetched `prefetch` deep;
+* target histograms are computed on the GPU (one launch per full-resolution image, sizes differ) and CACHED per
+  image on the device: the histogram of image i never changes, so after the first pass over the folder a batch's
+  targets are two gathers and one interpolation -- the reference's "precompute histograms.npy" flow
+  (create_hist_data.py:33-55) done lazily;
+* nothing touches the CPU histogram path.
 """
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import numpy as np
@@ -14,7 +23,7 @@ import torch
 EXTS = ['jpg', 'png']
 
 
-def _load_rgb(path, size=None):
+def _load_rgb(path, size=None, flip=False):
     from PIL import Image
     img = Image.open(path).convert('RGB')
     if size is not None:
@@ -24,15 +33,18 @@ def _load_rgb(path, size=None):
         w, h = img.size
         l, t = (w - size) // 2, (h - size) // 2                # transforms.CenterCrop(size)
         img = img.crop((l, t, l + size, t + size))
-    return torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0).permute(2, 0, 1).contiguous()  # ToTensor
+    arr = np.asarray(img, dtype=np.float32) / 255.0            # ToTensor
+    if flip:
+        arr = arr[:, ::-1]                                     # transforms.RandomHorizontalFlip
+    return torch.from_numpy(np.ascontiguousarray(arr)).permute(2, 0, 1).contiguous()
 
 
 class FolderData:
     def __init__(self, folder, hist_block, batch_size, image_size, device, transparent=False, seed=0, test=False,
-                 hist_sampling=True):
+                 hist_sampling=True, workers=8, prefetch=3, cache_hists=True, max_cached=200000, hflip=False):
         if transparent:
             raise NotImplementedError('transparent (RGBA) images are not supported')
-        self.paths = [p for ext in EXTS for p in Path(f'{folder}').glob(f'**/*.{ext}')]
+        self.paths = sorted(p for ext in EXTS for p in Path(f'{folder}').glob(f'**/*.{ext}'))
         if not self.paths:
             raise FileNotFoundError(f'no {EXTS} images under {folder}')
         self.hist_block, self.B, self.S, self.device, self.test = hist_block, batch_size, image_size, device, test
@@ -40,31 +52,67 @@ class FolderData:
         # True: target = interpolation of the histograms of two OTHER random images; False: the image's own
         # histogram (ReHistoGAN/rehistoGAN.py:375-446, `hist_sampling`)
         self.hist_sampling = hist_sampling
+        self.hflip = hflip                                      # the reference's training transform flips with p = 0.5
+        self.cache = {} if cache_hists else None
+        self.max_cached = max_cached
+        self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
+        self.queue = deque()
+        self.prefetch = max(1, prefetch)
+        self.hits = self.misses = 0
 
-    def _hist_of(self, idx):
-        # full-resolution images differ in size: one GPU call per image, still no CPU histogram
-        hs = []
-        for i in idx:
-            x = _load_rgb(self.paths[i]).unsqueeze(0).to(self.device)
-            with torch.no_grad():
-                hs.append(self.hist_block(x))
-        return torch.cat(hs, 0)
+    # ---- planning (host RNG, main thread: deterministic for a seed) and decoding (worker threads)
+    def _plan(self):
+        n = len(self.paths)
+        plan = {'img': self.rs.randint(0, n, self.B)}
+        own = self.test or not self.hist_sampling              # target = the image's own histogram
+        if not own:
+            plan['h1'], plan['h2'] = self.rs.randint(0, n, self.B), self.rs.randint(0, n, self.B)
+            plan['ratio'] = self.rs.rand(self.B).astype(np.float32)       # hist_interpolation (:180-182), per item
+        flips = self.rs.rand(self.B) < 0.5 if (self.hflip and not self.test) else np.zeros(self.B, bool)
+        need = set(int(i) for key in (('img',) if own else ('h1', 'h2')) for i in plan[key])
+        if self.cache is not None:
+            need = {i for i in need if i not in self.cache}
+        plan['full'] = {i: self.pool.submit(_load_rgb, self.paths[i]) for i in sorted(need)}   # full resolution
+        plan['small'] = None if self.test else [self.pool.submit(_load_rgb, self.paths[int(i)], self.S, bool(f))
+                                                for i, f in zip(plan['img'], flips)]
+        return plan
+
+    def _hist(self, idx, plan):
+        """(len(idx), 3, h, h) target histograms on the device: cached, or one GPU launch per missing image."""
+        out = []
+        for i in (int(v) for v in idx):
+            h = self.cache.get(i) if self.cache is not None else None
+            if h is None:
+                fut = plan['full'].get(i)
+                x = (fut.result() if fut is not None else _load_rgb(self.paths[i])).unsqueeze(0).to(self.device)
+                with torch.no_grad():
+                    h = self.hist_block(x)[0]
+                self.misses += 1
+                if self.cache is not None and len(self.cache) < self.max_cached:
+                    self.cache[i] = h
+            else:
+                self.hits += 1
+            out.append(h)
+        return torch.stack(out)
 
     def __iter__(self):
         return self
 
     def __next__(self):
-        n = len(self.paths)
-        if self.test:
-            return {'histograms': self._hist_of(self.rs.randint(0, n, self.B))}
-        idx = self.rs.randint(0, n, self.B)
-        images = torch.stack([_load_rgb(self.paths[i], self.S) for i in idx]).to(self.device)
-        if not self.hist_sampling:
-            return {'images': images, 'histograms': self._hist_of(idx)}
-        h1 = self._hist_of(self.rs.randint(0, n, self.B))
-        h2 = self._hist_of(self.rs.randint(0, n, self.B))
-        ratio = torch.rand(self.B, 1, 1, 1, device=self.device)   # hist_interpolation (:180-182), per item
-        return {'images': images, 'histograms': h1 * ratio + h2 * (1 - ratio)}
+        while len(self.queue) < self.prefetch:
+            self.queue.append(self._plan())
+        plan = self.queue.popleft()
+        batch = {}
+        if plan['small'] is not None:
+            host = torch.stack([f.result() for f in plan['small']])
+            batch['images'] = host.pin_memory().to(self.device, non_blocking=True) if self.device.type == 'cuda' \
+                else host.to(self.device)
+        if 'h1' in plan:
+            ratio = torch.from_numpy(plan['ratio']).to(self.device).view(-1, 1, 1, 1)
+            batch['histograms'] = self._hist(plan['h1'], plan) * ratio + self._hist(plan['h2'], plan) * (1 - ratio)
+        else:
+            batch['histograms'] = self._hist(plan['img'], plan)
+        return batch
 
 
 def save_image_grid(images, path, nrow=4, padding=2):

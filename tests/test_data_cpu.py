@@ -1,0 +1,76 @@
+"""Image-folder source: item contract, determinism, histogram cache, prefetch.
+The histogram block is a stand-in here (no GPU); tests/test_trainer_io_gpu.py runs the real one."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from histogan_amd.data import FolderData, _load_rgb, save_image_grid
+
+
+class FakeHist:
+    def __init__(self):
+        self.calls = 0
+
+    def __call__(self, x):
+        self.calls += 1
+        assert x.dim() == 4 and x.shape[0] == 1 and x.shape[1] == 3        # ONE full-resolution image per call
+        return x.mean(dim=(2, 3)).view(1, 3, 1, 1).expand(1, 3, 4, 4) / 3.0
+
+
+@pytest.fixture()
+def folder(tmp_path):
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    for i in range(7):
+        arr = (rs.rand(30 + i, 40 + 2 * i, 3) * 255).astype(np.uint8)
+        Image.fromarray(arr).save(os.path.join(tmp_path, f'im{i}.png' if i % 2 else f'im{i}.jpg'))
+    Image.fromarray((rs.rand(20, 20) * 255).astype(np.uint8)).save(os.path.join(tmp_path, 'grey.png'))   # greyscale
+    return str(tmp_path)
+
+
+def test_contract_determinism_and_cache(folder):
+    dev = torch.device('cpu')
+    h1, h2 = FakeHist(), FakeHist()
+    a = FolderData(folder, h1, 3, 16, dev, seed=1)
+    b = FolderData(folder, h2, 3, 16, dev, seed=1, workers=1, prefetch=1)
+    for _ in range(8):
+        x, y = next(a), next(b)
+        assert x['images'].shape == (3, 3, 16, 16) and x['histograms'].shape == (3, 3, 4, 4)
+        assert float(x['images'].min()) >= 0.0 and float(x['images'].max()) <= 1.0
+        assert torch.equal(x['images'], y['images']) and torch.equal(x['histograms'], y['histograms'])
+    # 8 images in the folder: every target histogram is computed exactly once, the rest are cache hits
+    assert h1.calls == len(a.cache) <= 8 and a.hits + a.misses == 8 * 3 * 2 and a.misses == h1.calls
+    c = FolderData(folder, FakeHist(), 3, 16, dev, seed=1, cache_hists=False)
+    assert torch.equal(next(c)['histograms'], next(FolderData(folder, FakeHist(), 3, 16, dev, seed=1))['histograms'])
+
+
+def test_modes(folder):
+    dev = torch.device('cpu')
+    t = next(FolderData(folder, FakeHist(), 2, 16, dev, seed=2, test=True))
+    assert set(t) == {'histograms'} and t['histograms'].shape == (2, 3, 4, 4)
+    own = FolderData(folder, FakeHist(), 4, 16, dev, seed=3, hist_sampling=False)
+    batch = next(own)
+    # own histogram: equals the stand-in applied to the full-resolution image of the same index
+    idx = np.random.RandomState(3).randint(0, len(own.paths), 4)
+    for k, i in enumerate(idx):
+        full = _load_rgb(own.paths[i]).unsqueeze(0)
+        assert torch.allclose(batch['histograms'][k], FakeHist()(full)[0])
+    with pytest.raises(FileNotFoundError):
+        FolderData(folder + '/nothing_here', FakeHist(), 1, 16, dev)
+    with pytest.raises(NotImplementedError):
+        FolderData(folder, FakeHist(), 1, 16, dev, transparent=True)
+
+
+def test_resize_crop_flip_and_grid(folder, tmp_path):
+    p = sorted(os.listdir(folder))[1]
+    full = _load_rgb(os.path.join(folder, p))
+    small = _load_rgb(os.path.join(folder, p), 16)
+    assert full.shape[0] == 3 and small.shape == (3, 16, 16)
+    assert torch.equal(_load_rgb(os.path.join(folder, p), 16, flip=True), torch.flip(small, dims=(2,)))
+    assert _load_rgb(os.path.join(folder, 'grey.png')).shape[0] == 3          # expand_greyscale
+    out = os.path.join(tmp_path, 'grid.png')
+    save_image_grid(torch.rand(5, 3, 8, 8), out, nrow=4)
+    from PIL import Image
+    assert Image.open(out).size == (4 * 10 + 2, 2 * 10 + 2)
