@@ -34,6 +34,9 @@
 #endif
 #ifndef HG_CONV_KC
 #define HG_CONV_KC 4
+#ifndef HG_WGRAD_TAPSPLIT
+#define HG_WGRAD_TAPSPLIT 2   // k_wgrad 2x2-tile blocks: the three kernel rows on three waves (12 waves, 3 per SIMD)
+#endif
 #ifndef HG_CONV_BIGTILE_SPLITK
 #define HG_CONV_BIGTILE_SPLITK 1
 #endif     // input channels per K chunk of the stride-1 tiles (64x64 tile: twice that); 2/4/8 measure within 3 %
@@ -405,11 +408,17 @@ struct CGeom {
 // waves of a tile split the pixel pairs of each chunk between them and write separate slabs.  The next
 // chunk is fetched into registers while the MFMAs of the current one run (the kernel is allowed the full
 // 512-register budget: accumulators in AGPRs, staging in VGPRs).
-template <int WN, int WK, int WS, int TAPS, int PC, int LTW, int IS, int MT>
-__global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
+// TS = 3 (3x3 only): the three kernel ROWS of a tile go to three different waves (3 x 16 accumulator registers each,
+// 12 waves per 2x2-tile block).  The 9-tap tile leaves room for ONE wave per SIMD (144 accumulators + staging), so every
+// s_waitcnt / barrier / staging instruction of that wave idles the matrix pipe (measured MFMA utilisation 0.62); with
+// three lighter waves per SIMD another wave's MFMAs fill those gaps.
+template <int WN, int WK, int WS, int TAPS, int PC, int LTW, int IS, int MT, int TS = 1>
+__global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a) {
   typedef MfmaTile<MT> M;
+  static_assert(TS == 1 || (TS == 3 && TAPS == 9), "tap split: rows of the 3x3 kernel");
+  constexpr int TPW = TAPS / TS;   // taps per wave
   constexpr int KS = M::KS;     // pixels per MFMA
-  constexpr int NT = WN * WK * WS * 64;
+  constexpr int NT = WN * WK * WS * TS * 64;
   constexpr int NBW = WN * MT;  // out channels (gout) per block
   constexpr int KBW = WK * MT;  // in channels per block
   constexpr int PAD = TAPS == 9 ? 1 : 0;
@@ -423,14 +432,15 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane % MT, lk = lane / MT;
   static_assert((1 << LTW) >= KS, "the pixels of one MFMA k-step must lie in one tile row");
-  const int wn = wave % WN, wk = (wave / WN) % WK, ws = wave / (WN * WK);
+  const int wn = wave % WN, wk = (wave / WN) % WK, ws = (wave / (WN * WK)) % WS, wt = wave / (WN * WK * WS);
+  const int t0 = wt * TPW;   // first tap of this wave
   const int Hi = a.Hi, Wi = a.Wi, Ho = a.Ho, Wo = a.Wo, K = a.K, N = a.N;
   const int HWi = Hi * Wi, HWo = Ho * Wo;
   const int k0 = (blockIdx.x % a.ktiles) * KBW, n0 = (blockIdx.x / a.ktiles) * NBW;
 
-  typename M::acc_t acc[TAPS];
+  typename M::acc_t acc[TPW];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int r = 0; r < M::NR; ++r) acc[t][r] = 0.f;
 
@@ -542,17 +552,20 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
     for (int q = 0; q < PC / KS / WS; ++q) {
       // this wave's pixel group (KS pixels of one row): compile-time when WS == 1, else one of WS alternatives
       float av;
-      float bv[TAPS];
+      float bv[TPW];
       auto rd = [&](int p0) __attribute__((always_inline)) {
         const int hoff = (p0 / (G::TW * G::TH)) * G::IMS + ((p0 / G::TW) % G::TH) * IS * G::TWp + (p0 % G::TW) * IS;
         av = Gc[p0];
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) bv[t] = Xc[hoff + (PAD ? (t / 3) * G::TWp + (t % 3) : 0)];
+        for (int t = 0; t < TPW; ++t) {
+          if constexpr (TS == 1) bv[t] = Xc[hoff + (PAD ? (t / 3) * G::TWp + (t % 3) : 0)];
+          else bv[t] = Xc[hoff + wt * G::TWp + t];   // kernel row wt, column t
+        }
       };
       if constexpr (WS == 1) rd(q * KS);
       else rd((q * WS + ws) * KS);
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) acc[t] = M::mma(av, bv[t], acc[t]);
+      for (int t = 0; t < TPW; ++t) acc[t] = M::mma(av, bv[t], acc[t]);
     }
   };
 
@@ -585,7 +598,7 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
   }
 
   if (a.gw != nullptr) {  // WS == 1 and one split: this block's tile IS the result
-    if constexpr (WS == 1 && MT == 32 && TAPS == 9) {
+    if constexpr (WS == 1 && MT == 32 && TAPS == 9 && TS == 1) {
       if ((K & 3) == 0) {
         // The (n, k, tap) layout makes a wave's 32n x 32k x 9 tile 32 contiguous 1152-byte runs: transpose it through
         // LDS and store 16-byte pieces (the direct store below writes 4-byte pieces at a 36-byte stride: 0.5 TB/s on
@@ -611,24 +624,24 @@ __global__ __launch_bounds__(WN *WK *WS * 64) void k_wgrad(const WgradArgs a) {
       }
     }
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < TPW; ++t)
 #pragma unroll
       for (int r = 0; r < M::NR; ++r) {
         const int n = n0 + wn * MT + M::row(r, lk);
         const int k = k0 + wk * MT + lm;
-        if (n < N && k < K) a.gw[((size_t)n * K + k) * TAPS + t] = acc[t][r];
+        if (n < N && k < K) a.gw[((size_t)n * K + k) * TAPS + t0 + t] = acc[t][r];
       }
     return;
   }
   // slab[split*WS + ws][t][n][k]: D[i = n][j = k]
   float *sb = a.slab + ((size_t)blockIdx.y * WS + ws) * TAPS * a.Np32 * a.Kp32;
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int r = 0; r < M::NR; ++r) {
       const int n = n0 + wn * MT + M::row(r, lk);
       const int k = k0 + wk * MT + lm;
-      sb[((size_t)t * a.Np32 + n) * a.Kp32 + k] = acc[t][r];
+      sb[((size_t)(t0 + t) * a.Np32 + n) * a.Kp32 + k] = acc[t][r];
     }
 }
 
@@ -938,7 +951,7 @@ WgradPlan make_wgrad_plan(int B, int K, int N, int Hi, int Wi, int ksize, int st
   return p;
 }
 
-template <int WN, int WK, int WS, int TAPS, int LTW, int IS, int MT = 32>
+template <int WN, int WK, int WS, int TAPS, int LTW, int IS, int MT = 32, int TS = 1>
 int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
   constexpr int PC = IS == 2 ? 32 : ((MT == 16 && LTW >= 3) ? 128 : 64);
   using G = CGeom<PC, LTW, TAPS == 9 ? 1 : 0, IS>;
@@ -948,12 +961,12 @@ int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
     const size_t need = (size_t)WN * WK * 32 * WG_TP * sizeof(float);
     if (need > lds) lds = need;
   }
-  auto kern = k_wgrad<WN, WK, WS, TAPS, PC, LTW, IS, MT>;
+  auto kern = k_wgrad<WN, WK, WS, TAPS, PC, LTW, IS, MT, TS>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.ktiles * p.ntiles), (unsigned)p.splits), dim3(WN * WK * WS * 64), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.ktiles * p.ntiles), (unsigned)p.splits), dim3(WN * WK * WS * TS * 64), lds, st, a);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
@@ -963,8 +976,24 @@ int launch_wgrad_g(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
   if constexpr (LTW >= 2) {
     if (p.MT == 16) return launch_wgrad_k<1, 1, 4, TAPS, LTW, IS, 16>(a, p, st);
   }
-  if (p.WN == 2 && p.WK == 2) return launch_wgrad_k<2, 2, 1, TAPS, LTW, IS>(a, p, st);
+  if (p.WN == 2 && p.WK == 2) {
+#if HG_WGRAD_TAPSPLIT
+    if constexpr (TAPS == 9 && IS == 1) {
+      if (a.gw == nullptr) return launch_wgrad_k<2, 2, 1, TAPS, LTW, IS, 32, 3>(a, p, st);   // slab path: rows split over waves
+    }
+#endif
+    return launch_wgrad_k<2, 2, 1, TAPS, LTW, IS>(a, p, st);
+  }
   if constexpr (IS == 1) {
+#if HG_WGRAD_TAPSPLIT > 1
+    if constexpr (TAPS == 9) {
+      if (a.gw == nullptr) {
+        if (p.WN == 2) return launch_wgrad_k<2, 1, 2, TAPS, LTW, IS, 32, 3>(a, p, st);
+        if (p.WK == 2) return launch_wgrad_k<1, 2, 2, TAPS, LTW, IS, 32, 3>(a, p, st);
+        return launch_wgrad_k<1, 1, 4, TAPS, LTW, IS, 32, 3>(a, p, st);
+      }
+    }
+#endif
     if (p.WN == 2) return launch_wgrad_k<2, 1, 2, TAPS, LTW, IS>(a, p, st);
     if (p.WK == 2) return launch_wgrad_k<1, 2, 2, TAPS, LTW, IS>(a, p, st);
   }
