@@ -34,6 +34,9 @@
 #endif
 #ifndef HG_CONV_KC
 #define HG_CONV_KC 4
+#ifndef HG_WGRAD_TS_DBUF
+#define HG_WGRAD_TS_DBUF 0   // double-buffering the tap-split pixel-split tiles: measured no gain
+#endif
 #ifndef HG_WGRAD_TAPSPLIT
 #define HG_WGRAD_TAPSPLIT 2   // k_wgrad 2x2-tile blocks: the three kernel rows on three waves (12 waves, 3 per SIMD)
 #endif
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a
   // buffer (it&1), the registers holding chunk c+1 are stored into the other buffer and re-filled with chunk c+2.
   constexpr int BUFSZ = NBW * GP + KBW * G::CHS;   // floats of one (gout + halo) buffer
   // (measured: +3..5 % for the 4-wave tiles; the pixel-split tiles (WS > 1) are faster single-buffered)
-  constexpr int NBUF = (WS == 1 && 2 * BUFSZ * 4 <= 160 * 1024) ? 2 : 1;
+  constexpr int NBUF = ((WS == 1 || (TS > 1 && HG_WGRAD_TS_DBUF)) && 2 * BUFSZ * 4 <= 160 * 1024) ? 2 : 1;
   auto store = [&](int buf) __attribute__((always_inline)) {
     float *G2 = smem + buf * BUFSZ, *X2 = G2 + NBW * GP;
 #pragma unroll
@@ -598,22 +601,22 @@ __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a
   }
 
   if (a.gw != nullptr) {  // WS == 1 and one split: this block's tile IS the result
-    if constexpr (WS == 1 && MT == 32 && TAPS == 9 && TS == 1) {
+    if constexpr (WS == 1 && MT == 32 && TAPS == 9) {
       if ((K & 3) == 0) {
         // The (n, k, tap) layout makes a wave's 32n x 32k x 9 tile 32 contiguous 1152-byte runs: transpose it through
         // LDS and store 16-byte pieces (the direct store below writes 4-byte pieces at a 36-byte stride: 0.5 TB/s on
         // the 151 MB gradient of a 2048x2048x3x3 layer).  The launch reserved 4 x 32 x WG_TP floats for this.
         __syncthreads();   // operand buffers are dead
-        float *T = smem + wave * 32 * WG_TP;
+        float *T = smem + (wave % (WN * WK)) * 32 * WG_TP;   // the TS waves of a tile fill one transpose buffer
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t)
+        for (int t = 0; t < TPW; ++t)
 #pragma unroll
-          for (int r = 0; r < M::NR; ++r) T[M::row(r, lk) * WG_TP + lm * 9 + t] = acc[t][r];
+          for (int r = 0; r < M::NR; ++r) T[M::row(r, lk) * WG_TP + lm * 9 + t0 + t] = acc[t][r];
         __syncthreads();
         const int kbase = k0 + wk * 32;
         const int nk = K - kbase < 32 ? K - kbase : 32;          // valid k's (multiple of 4)
         const int nf4 = nk > 0 ? nk * 9 / 4 : 0;                 // 16-byte pieces per row
-        for (int row = 0; row < 32; ++row) {
+        for (int row = wt; row < 32; row += TS) {
           const int n = n0 + wn * 32 + row;
           if (n >= N) break;
           float *dst = a.gw + ((size_t)n * K + kbase) * 9;
@@ -956,7 +959,7 @@ int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
   constexpr int PC = IS == 2 ? 32 : ((MT == 16 && LTW >= 3) ? 128 : 64);
   using G = CGeom<PC, LTW, TAPS == 9 ? 1 : 0, IS>;
   size_t lds = ((size_t)WN * MT * (PC + 1) + (size_t)WK * MT * G::CHS) * sizeof(float);
-  if (WS == 1 && 2 * lds <= 160 * 1024) lds *= 2;   // double buffered (NBUF in k_wgrad)
+  if ((WS == 1 || (TS > 1 && HG_WGRAD_TS_DBUF)) && 2 * lds <= 160 * 1024) lds *= 2;   // double buffered (NBUF in k_wgrad)
   if (a.gw != nullptr && WS == 1 && MT == 32 && TAPS == 9) {   // room for the store transpose of the single-slab case
     const size_t need = (size_t)WN * WK * 32 * WG_TP * sizeof(float);
     if (need > lds) lds = need;
@@ -979,7 +982,7 @@ int launch_wgrad_g(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
   if (p.WN == 2 && p.WK == 2) {
 #if HG_WGRAD_TAPSPLIT
     if constexpr (TAPS == 9 && IS == 1) {
-      if (a.gw == nullptr) return launch_wgrad_k<2, 2, 1, TAPS, LTW, IS, 32, 3>(a, p, st);   // slab path: rows split over waves
+      return launch_wgrad_k<2, 2, 1, TAPS, LTW, IS, 32, 3>(a, p, st);   // kernel rows split over waves
     }
 #endif
     return launch_wgrad_k<2, 2, 1, TAPS, LTW, IS>(a, p, st);
