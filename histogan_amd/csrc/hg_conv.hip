@@ -981,7 +981,7 @@ int launch_wgrad_g(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
   }
   if (p.WN == 2 && p.WK == 2) {
 #if HG_WGRAD_TAPSPLIT
-    if constexpr (TAPS == 9 && IS == 1) {
+    if constexpr (TAPS == 9) {
       return launch_wgrad_k<2, 2, 1, TAPS, LTW, IS, 32, 3>(a, p, st);   // kernel rows split over waves
     }
 #endif
@@ -1000,6 +1000,11 @@ int launch_wgrad_g(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
     if (p.WN == 2) return launch_wgrad_k<2, 1, 2, TAPS, LTW, IS>(a, p, st);
     if (p.WK == 2) return launch_wgrad_k<1, 2, 2, TAPS, LTW, IS>(a, p, st);
   }
+#if HG_WGRAD_TAPSPLIT > 1
+  if constexpr (TAPS == 9 && IS == 2) {
+    if (a.gw == nullptr) return launch_wgrad_k<1, 1, 4, TAPS, LTW, IS, 32, 3>(a, p, st);
+  }
+#endif
   return launch_wgrad_k<1, 1, 4, TAPS, LTW, IS>(a, p, st);
 }
 
