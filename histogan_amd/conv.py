@@ -349,15 +349,38 @@ class _ConvLrelu(torch.autograd.Function):
         return gx, gw, gb, None, None
 
 
+_I32 = 2 ** 31 - 1
+
+
+def _batch_pieces(x, w, stride):
+    """The kernels index activations with 32-bit element offsets: a batch whose input or output tensor has >= 2^31
+    elements (the 1024^2 configuration with attention: 16 x 512 x 512 x 512) is processed in batch slices (samples
+    are independent; autograd sums the weight gradients of the slices)."""
+    B, K, H, W = x.shape
+    per = max(K * H * W, w.shape[0] * _out_size(H, stride) * _out_size(W, stride))
+    if B * per <= _I32:
+        return 1
+    if per > _I32:
+        raise ValueError(f'conv2d: one sample of shape {tuple(x.shape[1:])} -> {w.shape[0]} channels exceeds 2^31 elements')
+    return -(-B // (_I32 // per))
+
+
+def _sliced(fn, x, w, stride):
+    n = _batch_pieces(x, w, stride)
+    if n == 1:
+        return fn(x)
+    return torch.cat([fn(xs) for xs in x.chunk(n, dim=0)], dim=0)
+
+
 def conv2d_lrelu(x, w, bias=None, slope=0.2):
     """leaky_relu(F.conv2d(x, w, bias, padding=k//2), slope) as one launch (stride 1)."""
-    return _ConvLrelu.apply(x, w, bias, 1, slope)
+    return _sliced(lambda t: _ConvLrelu.apply(t, w, bias, 1, slope), x, w, 1)
 
 
 def conv2d(x, w, bias=None, stride=1):
     """F.conv2d(x, w, bias, stride=stride, padding=k//2) for k in {1,3} on the MFMA implicit-GEMM kernels."""
-    return _Conv.apply(x, w, bias, stride)
+    return _sliced(lambda t: _Conv.apply(t, w, bias, stride), x, w, stride)
 
 
 def conv2d_same(x, w, bias=None):
-    return _Conv.apply(x, w, bias, 1)
+    return _sliced(lambda t: _Conv.apply(t, w, bias, 1), x, w, 1)

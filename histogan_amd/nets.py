@@ -255,27 +255,91 @@ class DiscriminatorBlock(nn.Module):
         return x
 
 
+class Residual(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        return self.fn(x) + x
+
+
+class Rezero(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+        self.g = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        return self.fn(x) * self.g
+
+
+class ImageLinearAttention(nn.Module):
+    """Linear attention over the pixels of a feature map, the discriminator's optional `attn_layers`
+    (reference histoGAN/histoGAN.py:594-596 imports it from the third-party `linear_attention_transformer`, whose source
+    is NOT in the reference tree and whose version is unpinned: restated from the published algorithm -- Shen et al.,
+    "Efficient Attention", as implemented in that package's images.py -- PARITY UNPINNED).
+
+        q, k, v = 1x1 convs of x -> (b, heads, d, n), n = h*w;   q, k *= d^-1/4
+        k = softmax over n;  q = softmax over d (norm_queries);  ctx = k v^T (d x e per head);  out = ctx^T q -> 1x1 conv
+
+    The four 1x1 convolutions run on the MFMA kernels (differentiable to any order: the gradient penalty goes through
+    them), the two softmaxes and the two small batched GEMMs (d = e = 64) are torch / rocBLAS ops."""
+
+    def __init__(self, chan, chan_out=None, kernel_size=1, padding=0, stride=1, key_dim=64, value_dim=64, heads=8,
+                 norm_queries=True):
+        super().__init__()
+        if kernel_size != 1 or padding != 0 or stride != 1:
+            raise NotImplementedError('ImageLinearAttention: only the 1x1 projections HistoGAN uses')
+        self.chan = chan
+        chan_out = chan if chan_out is None else chan_out
+        self.key_dim, self.value_dim, self.heads, self.norm_queries = key_dim, value_dim, heads, norm_queries
+        self.to_q = Conv2d(chan, key_dim * heads, 1)
+        self.to_k = Conv2d(chan, key_dim * heads, 1)
+        self.to_v = Conv2d(chan, value_dim * heads, 1)
+        self.to_out = Conv2d(value_dim * heads, chan_out, 1)
+
+    def forward(self, x, context=None):
+        if context is not None:
+            raise NotImplementedError('ImageLinearAttention: cross-attention context is not used by HistoGAN')
+        b, c, h, w = x.shape
+        heads = self.heads
+        q, k, v = self.to_q(x), self.to_k(x), self.to_v(x)
+        q, k, v = (t.reshape(b, heads, -1, h * w) for t in (q, k, v))
+        q, k = (t * (self.key_dim ** -0.25) for t in (q, k))
+        k = k.softmax(dim=-1)
+        if self.norm_queries:
+            q = q.softmax(dim=-2)
+        context = torch.einsum('bhdn,bhen->bhde', k, v)
+        out = torch.einsum('bhdn,bhde->bhen', q, context)
+        return self.to_out(out.reshape(b, -1, h, w))
+
+
 class Discriminator(nn.Module):
     def __init__(self, image_size, network_capacity=16, fq_layers=[], fq_dict_size=256, attn_layers=[],
                  transparent=False):
         super().__init__()
-        if list(fq_layers) or list(attn_layers):
-            raise NotImplementedError('fq_layers / attn_layers need vector_quantize_pytorch / '
-                                      'linear_attention_transformer (third-party, absent): not implemented')
+        if list(fq_layers):
+            raise NotImplementedError('fq_layers need vector_quantize_pytorch (third-party, absent): not implemented')
         num_layers = int(log2(image_size) - 1)
         num_init_filters = 3 if not transparent else 4
         filters = [num_init_filters] + [network_capacity * (2 ** i) for i in range(num_layers + 1)]
         chan_in_out = list(zip(filters[0:-1], filters[1:]))
         self.blocks = nn.ModuleList([DiscriminatorBlock(i, o, downsample=ind != (len(chan_in_out) - 1))
                                      for ind, (i, o) in enumerate(chan_in_out)])
-        self.attn_blocks = nn.ModuleList([None for _ in chan_in_out])
+        attn_layers = [int(a) for a in attn_layers]
+        self.attn_blocks = nn.ModuleList([
+            nn.Sequential(*[Residual(Rezero(ImageLinearAttention(o))) for _ in range(2)])
+            if ind + 1 in attn_layers else None for ind, (i, o) in enumerate(chan_in_out)])
         self.quantize_blocks = nn.ModuleList([None for _ in chan_in_out])
         self.flatten = Flatten()
         self.to_logit = nn.Linear(2 * 2 * filters[-1], 1)
 
     def forward(self, x):
         quantize_loss = torch.zeros(1).to(x)
-        for block in self.blocks:
+        for block, attn_block in zip(self.blocks, self.attn_blocks):
             x = block(x)
+            if attn_block is not None:
+                x = attn_block(x)
         x = self.to_logit(self.flatten(x))
         return x.squeeze(), quantize_loss

@@ -10,7 +10,7 @@ Follows (cites relative to the reference root):
 * rgb_block ............. histoGAN/histoGAN.py:380-390
 * generator_block ....... histoGAN/histoGAN.py:461-479  (noise permute (0,3,2,1): H<->W swapped)
 * generator ............. histoGAN/histoGAN.py:558-568
-* discriminator[_block] . histoGAN/histoGAN.py:520-526, 613-631 (no attention / VQ layers)
+* discriminator[_block] . histoGAN/histoGAN.py:520-526, 613-631 (no VQ layers; attention: see image_linear_attention)
 * vectorizer ............ histoGAN/histoGAN.py:335-365
 * gradient_penalty ...... histoGAN/histoGAN.py:156-163
 * diffgrad_step ......... torch_optimizer.DiffGrad (third-party, source NOT in the reference tree,
@@ -75,6 +75,20 @@ def generator(sd, styles, hists, noise, num_layers):
     return rgb
 
 
+def image_linear_attention(sd, pre, x, key_dim=64, heads=8):
+    """linear_attention_transformer.images.ImageLinearAttention (third-party, not in the reference tree, version
+    unpinned: restated from the published algorithm -- PARITY UNPINNED); defaults as the reference calls it
+    (histoGAN/histoGAN.py:594-596: 1x1 projections, key_dim = value_dim = 64, heads = 8, norm_queries)."""
+    b, c, h, w = x.shape
+    q, k, v = (F.conv2d(x, sd[f'{pre}to_{n}.weight'], sd[f'{pre}to_{n}.bias']).reshape(b, heads, -1, h * w) for n in 'qkv')
+    q, k = q * key_dim ** -0.25, k * key_dim ** -0.25
+    k = k.softmax(dim=-1)
+    q = q.softmax(dim=-2)
+    ctx = torch.einsum('bhdn,bhen->bhde', k, v)
+    out = torch.einsum('bhdn,bhde->bhen', q, ctx).reshape(b, -1, h, w)
+    return F.conv2d(out, sd[pre + 'to_out.weight'], sd[pre + 'to_out.bias'])
+
+
 def discriminator(sd, x, num_blocks):
     for i in range(num_blocks):
         p = f'blocks.{i}.'
@@ -84,6 +98,10 @@ def discriminator(sd, x, num_blocks):
         x = x + res
         if p + 'downsample.weight' in sd:
             x = F.conv2d(x, sd[p + 'downsample.weight'], sd[p + 'downsample.bias'], padding=1, stride=2)
+        for j in range(2):     # Residual(Rezero(ImageLinearAttention)) x 2 on the layers named in attn_layers (:594-596)
+            a = f'attn_blocks.{i}.{j}.fn.'
+            if a + 'g' in sd:
+                x = image_linear_attention(sd, a + 'fn.', x) * sd[a + 'g'] + x
     x = x.reshape(x.shape[0], -1)
     return _lin(sd, 'to_logit', x).squeeze()
 

@@ -347,3 +347,48 @@ def test_modconv_stage_matches_unfused(K, N, H, up, demod, act, gpu_device):
     gr = torch.autograd.grad(ref, dd[:len(ins)], go.double())
     for a, b in zip(gm, gr):
         assert relmax(a.cpu().numpy(), b.cpu().numpy()) <= 1e-4
+
+
+def test_discriminator_with_attention_matches_oracle(gpu_device):
+    """attn_layers: Residual(Rezero(ImageLinearAttention)) x 2 after the named blocks (reference :594-596), forward,
+    gradient penalty (double backward through the attention) and parameter gradients against the oracle restatement
+    (third-party algorithm: parity unpinned, see oracle/histogan_nets.py)."""
+    from histoGAN import Discriminator
+    from histoGAN.histoGAN import gradient_penalty
+    from oracle import histogan_nets as N
+    torch.manual_seed(4)
+    D = Discriminator(32, network_capacity=2, attn_layers=[1, 3]).to(gpu_device)
+    with torch.no_grad():
+        for k, v in D.named_parameters():
+            if k.endswith('.g'):
+                v.fill_(0.6)                         # Rezero gates start at 0: open them
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in D.state_dict().items()}
+    assert any(k.startswith('attn_blocks.0.1.fn.fn.to_out') for k in sd) and 'attn_blocks.1.0.fn.g' not in sd
+    img = torch.rand(3, 3, 32, 32)
+    x = img.clone().to(gpu_device).requires_grad_(True)
+    logits, q = D(x)
+    loss = torch.relu(1 + logits).mean() + gradient_penalty(x, logits)
+    xc = img.clone().requires_grad_(True)
+    ref_logits = N.discriminator(sd, xc, 5)
+    ref_loss = torch.relu(1 + ref_logits).mean() + N.gradient_penalty(xc, ref_logits)
+    assert relmax(logits.detach().cpu().numpy(), ref_logits.detach().numpy()) <= 1e-5
+    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * max(1.0, abs(float(ref_loss)))
+    names = ['attn_blocks.0.0.fn.fn.to_q.weight', 'attn_blocks.0.1.fn.fn.to_out.bias', 'attn_blocks.2.0.fn.g',
+             'attn_blocks.2.1.fn.fn.to_v.weight', 'blocks.0.net.0.weight', 'blocks.3.conv_res.weight', 'to_logit.weight']
+    params = dict(D.named_parameters())
+    grads = torch.autograd.grad(loss, [params[n] for n in names])
+    refs = torch.autograd.grad(ref_loss, [sd[n] for n in names])
+    for n, a, b in zip(names, grads, refs):
+        assert relmax(a.cpu().numpy(), b.numpy()) <= 2e-4, n
+
+
+def test_train_steps_with_attention(gpu_device, tmp_path):
+    from histoGAN import Trainer
+    tr = Trainer('attn', tmp_path / 'r', tmp_path / 'm', 32, 2, batch_size=2, hist_bin=16, hist_insz=32,
+                 hist_resizing='interpolation', attn_layers=[1, 2])
+    tr.run_evaluate = tr.run_save = False
+    tr.set_synthetic_data_src()
+    for _ in range(2):
+        tr.train(alpha=2)
+    assert np.isfinite(tr.d_loss) and np.isfinite(tr.g_loss) and np.isfinite(tr.last_gp_loss)
+    assert any('attn_blocks.0.0.fn.fn.to_q.weight' in k for k in tr.GAN.state_dict())
