@@ -614,16 +614,21 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
 // one pixel per lane, fp64 kernel evaluation, fp32 mat-vecs against Ghat held in global/L2 (every
 // lane reads the same Ghat element -> one broadcast load).  Used where the MFMA kernel does not
 // apply (h > 64 or an asymmetric boundary); ~10x slower per pixel but exact in structure.
-__global__ __launch_bounds__(256) void k_hist_ghat(const float *__restrict__ gout, const float *__restrict__ hist,
-                                                   const float *__restrict__ sums, float *__restrict__ gh, int n) {
-  __shared__ float sm4[4];
+__global__ __launch_bounds__(1024) void k_hist_ghat(const float *__restrict__ gout, const float *__restrict__ hist,
+                                                    const float *__restrict__ sums, float *__restrict__ gh, int n) {
+  __shared__ float sm16[16];
   const int b = blockIdx.x;
   const float *g = gout + (long long)b * n, *o = hist + (long long)b * n;
   float d = 0.f;
-  for (int e = threadIdx.x; e < n; e += 256) d = fmaf(g[e], o[e], d);
-  d = hg_block_sum_256(d, sm4);
+  for (int e = threadIdx.x; e < n; e += 1024) d = fmaf(g[e], o[e], d);
+  d = hg_wave_sum(d);
+  if ((threadIdx.x & 63) == 0) sm16[threadIdx.x >> 6] = d;
+  __syncthreads();
+  d = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) d += sm16[w];      // fixed order: deterministic
   const float inv = 1.f / sums[b];
-  for (int e = threadIdx.x; e < n; e += 256) gh[(long long)b * n + e] = (g[e] - d) * inv;
+  for (int e = threadIdx.x; e < n; e += 1024) gh[(long long)b * n + e] = (g[e] - d) * inv;
 }
 
 template <int METHOD>
@@ -693,6 +698,148 @@ __global__ __launch_bounds__(64) void k_hist_bwd_generic(const DevParams P, cons
     if (P.mode == HG_RESIZE_NONE)
       for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Thresholding (RGBuvHistBlock.py:116-124): the kernel is a 0/1 window of width eps around each bin centre, so a
+// pixel touches (normally) ONE bin per plane -- a true scatter-add histogram, HBM-bound, not the dense h x h
+// product of the smooth kernels.  One workgroup takes a pixel range of one image and, plane after plane, bins it
+// into an h x h LDS grid with 64-bit FIXED-POINT atomics (Iy * 2^32): integer sums are order-independent, so the
+// result is deterministic (and more accurate than an fp32 running sum); the grid is flushed as a float slab in the
+// layout of k_hist_fwd (k_hist_reduce / k_hist_normalize finish as usual).  Pixels are re-projected per plane
+// (their second and third read hit L2).
+constexpr double kThrScale = 4294967296.0;   // 2^32
+
+// candidate bin range [lo_i, hi_i] for |u - b_i| <= eps/2 (one spare bin either side; hits are decided by thr_hit);
+// inv_step = 1/step, w = half_eps/step (0 when step == 0: single bin)
+__device__ __forceinline__ void thr_range(const DevParams &P, float u, double inv_step, double w, int &lo_i, int &hi_i) {
+  if (P.h == 1 || !(P.step > 0.0)) { lo_i = 0; hi_i = P.h - 1; return; }
+  const double t = ((double)u - P.lo) * inv_step;
+  const double a = floor(t - w) - 1.0, b = ceil(t + w) + 1.0;
+  lo_i = a < 0.0 ? 0 : (a > (double)(P.h - 1) ? P.h : (int)a);
+  hi_i = b > (double)(P.h - 1) ? P.h - 1 : (b < 0.0 ? -1 : (int)b);
+}
+
+__device__ __forceinline__ bool thr_hit(const DevParams &P, float u, int i) {
+  return fabs((double)u - bin_center(P, i)) <= P.half_eps;    // the reference's fp64 comparison, bit for bit
+}
+
+// single: the windows are narrower than the bin spacing (every symmetric boundary: eps = (hi-lo)/h < (hi-lo)/(h-1)), so
+// only the NEAREST bin can contain u -- and near a midpoint, where rounding could pick the other neighbour, neither does.
+__device__ __forceinline__ int thr_single(const DevParams &P, float u, double inv_step) {
+  const double t = ((double)u - P.lo) * inv_step;
+  if (!(t > -1.0 && t < (double)P.h)) return -1;
+  int i = (int)rint(t);
+  i = i < 0 ? 0 : (i > P.h - 1 ? P.h - 1 : i);
+  return thr_hit(P, u, i) ? i : -1;
+}
+
+__device__ __forceinline__ void thr_scatter_plane(const DevParams &P, unsigned long long *bins, float u, float v,
+                                                  double inv_step, double w, bool single, unsigned long long q) {
+  if (single) {
+    const int i = thr_single(P, u, inv_step), j = thr_single(P, v, inv_step);
+    if (i >= 0 && j >= 0) atomicAdd(&bins[i * P.h + j], q);
+    return;
+  }
+  int ul, uh, vl, vh;
+  thr_range(P, u, inv_step, w, ul, uh);
+  thr_range(P, v, inv_step, w, vl, vh);
+  for (int i = ul; i <= uh; ++i) {
+    if (!thr_hit(P, u, i)) continue;
+    for (int j = vl; j <= vh; ++j)
+      if (thr_hit(P, v, j)) atomicAdd(&bins[i * P.h + j], q);
+  }
+}
+
+// ALL3: the grids of all planes are in LDS at once (3 h^2 x 8 B <= 150 KB, h <= 79): every pixel is read and projected
+// (3 fp64 logs) ONCE; otherwise plane after plane through one grid (the 2nd / 3rd read of a pixel hits L2).
+template <bool ALL3>
+__global__ __launch_bounds__(ALL3 ? 1024 : 256) void k_hist_thr_fwd(const DevParams P, const float *__restrict__ x,
+                                                                    float *__restrict__ slabs, int per_block) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem);   // [planes][h][h]
+  constexpr int NT = ALL3 ? 1024 : 256;
+  const int b = blockIdx.y, s = blockIdx.x, S = gridDim.x, h = P.h, hh = h * h;
+  const float *xb = x + (long long)b * P.sb;
+  const int n0 = s * per_block, n1 = min(P.npix, n0 + per_block);
+  float *slab = slabs + ((long long)(b * S + s) * P.P) * hh;
+  const double inv_step = P.step > 0.0 ? 1.0 / P.step : 0.0, w = P.half_eps * inv_step;
+  const bool single = P.h > 1 && P.step > 2.0 * P.half_eps * (1.0 + 1e-9);
+  if constexpr (ALL3) {
+    for (int e = threadIdx.x; e < P.P * hh; e += NT) bins[e] = 0ull;
+    __syncthreads();
+    for (int n = n0 + threadIdx.x; n < n1; n += NT) {
+      float r, g, bl, a, bb, c, iy;
+      sample_rgb(P, xb, n, r, g, bl);
+      project(P, r, g, bl, a, bb, c, iy);
+      const unsigned long long q = (unsigned long long)((double)iy * kThrScale + 0.5);
+      if (P.green) {
+        thr_scatter_plane(P, bins, -a, c, inv_step, w, single, q);
+      } else {
+        thr_scatter_plane(P, bins, a, bb, inv_step, w, single, q);
+        thr_scatter_plane(P, bins + hh, -a, c, inv_step, w, single, q);
+        thr_scatter_plane(P, bins + 2 * hh, -bb, -c, inv_step, w, single, q);
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < P.P * hh; e += NT) slab[e] = (float)((double)bins[e] * (1.0 / kThrScale));
+  } else {
+    for (int p = 0; p < 3; ++p) {
+      if (P.green && p != 1) continue;
+      for (int e = threadIdx.x; e < hh; e += NT) bins[e] = 0ull;
+      __syncthreads();
+      for (int n = n0 + threadIdx.x; n < n1; n += NT) {
+        float r, g, bl, a, bb, c, iy;
+        sample_rgb(P, xb, n, r, g, bl);
+        project(P, r, g, bl, a, bb, c, iy);
+        const float u = p == 0 ? a : (p == 1 ? -a : -bb), v = p == 0 ? bb : (p == 1 ? c : -c);
+        thr_scatter_plane(P, bins, u, v, inv_step, w, single, (unsigned long long)((double)iy * kThrScale + 0.5));
+      }
+      __syncthreads();
+      float *dst = slab + (long long)(P.green ? 0 : p) * hh;
+      for (int e = threadIdx.x; e < hh; e += NT) dst[e] = (float)((double)bins[e] * (1.0 / kThrScale));
+      __syncthreads();
+    }
+  }
+}
+
+// Backward of the thresholding histogram: the window has zero slope, so the only path to the pixel is the weight Iy:
+// dL/dIy = sum over planes of Ghat at the pixel's bin(s) -- a gather -- and dx_c = dL/dIy * x_c / Iy (store_pixel_grad).
+__global__ __launch_bounds__(256) void k_hist_thr_bwd(const DevParams P, const float *__restrict__ x,
+                                                      const float *__restrict__ gh, float *__restrict__ gdst) {
+  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x, h = P.h;
+  if (n >= P.npix) return;
+  const float *xb = x + (long long)b * P.sb;
+  float r, g, bl, a, bb, c, iy;
+  sample_rgb(P, xb, n, r, g, bl);
+  project(P, r, g, bl, a, bb, c, iy);
+  float dIy = 0.f;
+  if (P.intensity) {
+    const double inv_step = P.step > 0.0 ? 1.0 / P.step : 0.0, w = P.half_eps * inv_step;
+    const bool single = P.h > 1 && P.step > 2.0 * P.half_eps * (1.0 + 1e-9);
+    for (int p = 0; p < 3; ++p) {
+      if (P.green && p != 1) continue;
+      const float *G = gh + ((long long)b * P.P + (P.green ? 0 : p)) * h * h;
+      const float u = p == 0 ? a : (p == 1 ? -a : -bb), v = p == 0 ? bb : (p == 1 ? c : -c);
+      if (single) {
+        const int i = thr_single(P, u, inv_step), j = thr_single(P, v, inv_step);
+        if (i >= 0 && j >= 0) dIy += G[i * h + j];
+        continue;
+      }
+      int ul, uh, vl, vh;
+      thr_range(P, u, inv_step, w, ul, uh);
+      thr_range(P, v, inv_step, w, vl, vh);
+      for (int i = ul; i <= uh; ++i) {
+        if (!thr_hit(P, u, i)) continue;
+        for (int j = vl; j <= vh; ++j)
+          if (thr_hit(P, v, j)) dIy += G[i * h + j];
+      }
+    }
+  }
+  if (P.proj != HG_PROJ_RGBUV) store_pixel_grad_proj(P, xb, b, n, r, g, bl, iy, 0.f, 0.f, dIy, gdst);
+  else store_pixel_grad(P, xb, b, n, r, g, bl, iy, 0.f, 0.f, 0.f, dIy, gdst);
+  if (P.mode == HG_RESIZE_NONE)
+    for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
 }
 
 // Adjoint of the bilinear resize (deterministic gather) fused with the clamp mask.
@@ -789,6 +936,11 @@ int validate(const hg_hist_params *p) {
   return HG_OK;
 }
 
+// thresholding runs on the scatter kernels when the h x h 64-bit LDS grid fits (h <= 140)
+inline bool thr_scatter(const hg_hist_params *p) {
+  return p->method == HG_METHOD_THRESHOLDING && (size_t)p->h * p->h * 8 <= 156 * 1024;
+}
+
 Plan make_plan(const hg_hist_params *p) {
   Plan pl;
   pl.T = (p->h <= 32) ? 1 : 2;
@@ -800,6 +952,8 @@ Plan make_plan(const hg_hist_params *p) {
   // forward: aim at ~2 workgroups per CU (256 CUs), >= 64 pixels per wave
   const long long wg_fixed = (long long)p->B * pl.nbd * pl.nbd;
   long long target = 512;
+  // the scatter kernel keeps up to 98 KB of LDS grids: one workgroup per CU is all that fits, more only add slabs
+  if (thr_scatter(p)) target = 256;
   if (const char *e = getenv("HG_FWD_WGS")) target = atoll(e) > 0 ? atoll(e) : target;  // tuning knob
   long long S = (target + wg_fixed - 1) / wg_fixed;
   const long long maxS = (npix + 255) / 256;
@@ -827,7 +981,7 @@ Plan make_plan(const hg_hist_params *p) {
   pl.S_bwd = (int)Sb;
   pl.rounds = (int)rpw;
   // generic backward only (h > 64 or asymmetric boundary): Ghat in natural layout
-  pl.gh_bytes = ((p->lo != -p->hi) || pl.nbd != 1 || p->projection) ? ((size_t)p->B * n_per_img * sizeof(float) + 255) / 256 * 256 : 256;
+  pl.gh_bytes = ((p->lo != -p->hi) || pl.nbd != 1 || p->projection || thr_scatter(p)) ? ((size_t)p->B * n_per_img * sizeof(float) + 255) / 256 * 256 : 256;
   pl.gxs_bytes = (p->resize_mode == HG_RESIZE_NONE) ? 0 : ((size_t)p->B * 3 * npix * sizeof(float) + 255) / 256 * 256;
   return pl;
 }
@@ -944,8 +1098,21 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
   float *partials = (float *)workspace;
   float *slabs = (float *)((char *)workspace + pl.part_bytes);
   const bool sym = (p->lo == -p->hi);
-  int r = (pl.T == 1) ? launch_fwd_t<1>(d, pl, sym, x, slabs, st) : launch_fwd_t<2>(d, pl, sym, x, slabs, st);
-  if (r) return r;
+  if (thr_scatter(p)) {
+    const size_t one = (size_t)d.h * d.h * sizeof(unsigned long long);
+    const bool all3 = one * d.P <= 150 * 1024;
+    const size_t lds = all3 ? one * d.P : one;
+    auto kern = all3 ? k_hist_thr_fwd<true> : k_hist_thr_fwd<false>;
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(pl.S_fwd, d.B), dim3(all3 ? 1024 : 256), lds, st, d, x, slabs, 4 * pl.chunk);
+    HG_LAUNCH_CHECK();
+  } else {
+    int r = (pl.T == 1) ? launch_fwd_t<1>(d, pl, sym, x, slabs, st) : launch_fwd_t<2>(d, pl, sym, x, slabs, st);
+    if (r) return r;
+  }
   const int n_per_img = d.P * d.h * d.h;
   hipLaunchKernelGGL(k_hist_reduce, dim3(pl.nparts, d.B), dim3(256), 0, st, slabs, hist_out, partials, pl.S_fwd, n_per_img);
   HG_LAUNCH_CHECK();
@@ -975,14 +1142,20 @@ int hg_rgbuv_hist_bwd(const hg_hist_params *p, const float *x, const float *grad
       if (e != hipSuccess) return (int)e;
     }
   }
-  if (!generic) {
+  if (thr_scatter(p)) {
+    float *gh = (float *)((char *)workspace + pl.gxs_bytes);
+    hipLaunchKernelGGL(k_hist_ghat, dim3(d.B), dim3(1024), 0, st, grad_out, hist_out, sum_out, gh, d.P * d.h * d.h);
+    HG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_hist_thr_bwd, dim3((d.npix + 255) / 256, d.B), dim3(256), 0, st, d, x, gh, gdst);
+    HG_LAUNCH_CHECK();
+  } else if (!generic) {
     int r = (pl.T == 1) ? launch_bwd_t<1>(d, pl, x, grad_out, hist_out, sum_out, gdst, st)
                         : launch_bwd_t<2>(d, pl, x, grad_out, hist_out, sum_out, gdst, st);
     if (r) return r;
   } else {
     float *gh = (float *)((char *)workspace + pl.gxs_bytes);
     const int n_per_img = d.P * d.h * d.h;
-    hipLaunchKernelGGL(k_hist_ghat, dim3(d.B), dim3(256), 0, st, grad_out, hist_out, sum_out, gh, n_per_img);
+    hipLaunchKernelGGL(k_hist_ghat, dim3(d.B), dim3(1024), 0, st, grad_out, hist_out, sum_out, gh, n_per_img);
     HG_LAUNCH_CHECK();
     const size_t lds = (size_t)d.h * 64 * sizeof(float);
     if (lds > 160 * 1024) return HG_EUNSUPPORTED;  // h > 640

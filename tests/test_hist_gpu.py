@@ -61,3 +61,38 @@ def test_hellinger_inline_formula_matches_kernel(gpu_device):
     (gours,) = torch.autograd.grad(ours, gen)
     assert abs(float(ours) - float(ref)) <= 1e-6
     assert relmax(gours.cpu().numpy(), gref.cpu().numpy()) <= 1e-5
+
+
+THR_CASES = [
+    dict(h=16, insz=64, intensity_scale=True),                                   # eps < bin spacing: one bin per pixel
+    dict(h=16, insz=64, intensity_scale=True, hist_boundary=[0.5, 3.0]),         # eps > spacing: two bins can hit
+    dict(h=33, insz=40, intensity_scale=False, resizing='interpolation'),        # counts only, odd h, resize
+    dict(h=128, insz=150, intensity_scale=True, green_only=True),                # 128 KB LDS grid
+    dict(h=8, insz=20, intensity_scale=True, resizing='sampling'),
+]
+
+
+@pytest.mark.parametrize('kw', THR_CASES)
+def test_thresholding_scatter_matches_oracle(kw, gpu_device):
+    """method='thresholding' runs on the scatter-add kernels (k_hist_thr_fwd / _bwd): parity with the oracle's dense
+    formulation, incl. boundaries where a value falls into two windows, and bit-identical repeat runs."""
+    from oracle import rgbuv_hist as O
+    g = torch.Generator().manual_seed(kw['h'])
+    x = (torch.rand(3, 3, 48, 56, generator=g) * 1.2 - 0.1)                      # some values outside [0, 1]
+    x[0, :, :4] = 0.0; x[1, :, 5:9, 5:9] = 1.0; x[2, 0] = 0.25                   # exact zeros / ones / constant plane
+    blk = _block(dict(method='thresholding', sigma=0.02, **kw))
+    xg = x.to(gpu_device).requires_grad_(True)
+    out = blk(xg)
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.to(gpu_device))
+    xo = x.clone().requires_grad_(True)
+    ref = O.rgbuv_hist(xo, method='thresholding', **kw)
+    assert out.shape == ref.shape
+    assert relmax(out.detach().cpu().numpy(), ref.detach().numpy()) <= FWD_TOL
+    if ref.requires_grad:
+        ref.backward(go)
+        assert relmax(xg.grad.cpu().numpy(), xo.grad.numpy()) <= BWD_TOL
+    else:                                # no intensity scale: the window has no slope, the reference has no gradient path
+        assert float(xg.grad.abs().max()) == 0.0
+    again = blk(x.to(gpu_device))
+    assert torch.equal(again, out.detach())                                      # integer LDS atomics: order-independent
