@@ -285,7 +285,10 @@ def main():
         # ranks (ranks then share a device; test use only)
         backend = os.environ.get('HG_DIST_BACKEND', 'nccl')
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            try:
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            except TypeError:        # older torch: no device_id argument
+                dist.init_process_group('nccl', rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
