@@ -96,3 +96,39 @@ def test_thresholding_scatter_matches_oracle(kw, gpu_device):
         assert float(xg.grad.abs().max()) == 0.0
     again = blk(x.to(gpu_device))
     assert torch.equal(again, out.detach())                                      # integer LDS atomics: order-independent
+
+
+def test_module_surface_matches_reference_contract(gpu_device):
+    """ctor kwargs / attributes, device variants, lazy bare Exceptions with the reference's
+    messages (RGBuvHistBlock.py:90-93, 141-144), empty state_dict, strided / double / C = 4 inputs."""
+    from histogram_classes.RGBuvHistBlock import RGBuvHistBlock
+    from oracle import rgbuv_hist as O
+    bnd = [3, -3]
+    m = RGBuvHistBlock(h=16, insz=32, resizing='sampling', method='thresholding', hist_boundary=bnd, device='cuda')
+    assert bnd == [-3, 3] and m.hist_boundary is bnd                      # sorted IN PLACE like the reference (:66-69)
+    assert m.eps == 6 / 16 and not hasattr(m, 'sigma') and len(m.state_dict()) == 0 and len(list(m.parameters())) == 0
+    m2 = RGBuvHistBlock(h=16, sigma=0.05)
+    assert (m2.h, m2.insz, m2.resizing, m2.method, m2.sigma, m2.intensity_scale, m2.green_only) == \
+        (16, 150, 'interpolation', 'inverse-quadratic', 0.05, True, False)
+    x = torch.rand(2, 4, 20, 28)                                           # C = 4: first three channels are used
+    ref = O.rgbuv_hist(x, h=16).numpy()
+    for dev_arg in ('cuda', 0, torch.device('cuda:0'), gpu_device):
+        out = RGBuvHistBlock(h=16, device=dev_arg)(x.to(gpu_device))
+        assert out.is_cuda and out.dtype == torch.float32 and relmax(out.cpu().numpy(), ref) <= FWD_TOL
+    assert relmax(RGBuvHistBlock(h=16)(x).cpu().numpy(), ref) <= FWD_TOL    # CPU tensor is moved to the module's GPU
+    assert relmax(RGBuvHistBlock(h=16)(x.double().to(gpu_device)).cpu().numpy(), ref) <= FWD_TOL
+    big = torch.rand(2, 4, 40, 56, device=gpu_device)
+    view = big[:, :, ::2, ::2]                                             # non-contiguous view
+    assert relmax(RGBuvHistBlock(h=16)(view).cpu().numpy(), O.rgbuv_hist(view.cpu(), h=16).numpy()) <= FWD_TOL
+    # bad arguments are accepted by the constructor and raise a bare Exception in forward, reference messages
+    with pytest.raises(Exception, match='Wrong kernel method'):
+        RGBuvHistBlock(h=16, method='gaussian')(x.to(gpu_device))
+    with pytest.raises(Exception, match='Wrong resizing method'):
+        RGBuvHistBlock(h=16, insz=8, resizing='nearest')(x.to(gpu_device))
+    RGBuvHistBlock(h=16, insz=64, resizing='nearest')(x.to(gpu_device))    # not reached when no resize is needed (:80-93)
+    with pytest.raises(RuntimeError):
+        RGBuvHistBlock(h=16, device='cpu')(x)
+    # sums to one over all planes; one plane when green_only
+    s = RGBuvHistBlock(h=16)(x.to(gpu_device)).sum(dim=(1, 2, 3))
+    assert torch.allclose(s, torch.ones_like(s), atol=1e-5)
+    assert RGBuvHistBlock(h=16, green_only=True)(x.to(gpu_device)).shape == (2, 1, 16, 16)
