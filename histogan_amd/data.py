@@ -23,9 +23,9 @@ import torch
 EXTS = ['jpg', 'png']
 
 
-def _load_rgb(path, size=None, flip=False):
+def _load_rgb(path, size=None, flip=False, rgba=False):
     from PIL import Image
-    img = Image.open(path).convert('RGB')
+    img = Image.open(path).convert('RGBA' if rgba else 'RGB')    # convert_rgb_to_transparent / _transparent_to_rgb
     if size is not None:
         w, h = img.size
         s = size / min(w, h)                                   # transforms.Resize(size): short side -> size
@@ -42,8 +42,7 @@ def _load_rgb(path, size=None, flip=False):
 class FolderData:
     def __init__(self, folder, hist_block, batch_size, image_size, device, transparent=False, seed=0, test=False,
                  hist_sampling=True, workers=8, prefetch=3, cache_hists=True, max_cached=200000, hflip=False):
-        if transparent:
-            raise NotImplementedError('transparent (RGBA) images are not supported')
+        self.rgba = bool(transparent)                            # 4-channel items; the histogram uses channels 0..2
         self.paths = sorted(p for ext in EXTS for p in Path(f'{folder}').glob(f'**/*.{ext}'))
         if not self.paths:
             raise FileNotFoundError(f'no {EXTS} images under {folder}')
@@ -72,8 +71,8 @@ class FolderData:
         need = set(int(i) for key in (('img',) if own else ('h1', 'h2')) for i in plan[key])
         if self.cache is not None:
             need = {i for i in need if i not in self.cache}
-        plan['full'] = {i: self.pool.submit(_load_rgb, self.paths[i]) for i in sorted(need)}   # full resolution
-        plan['small'] = None if self.test else [self.pool.submit(_load_rgb, self.paths[int(i)], self.S, bool(f))
+        plan['full'] = {i: self.pool.submit(_load_rgb, self.paths[i], None, False, self.rgba) for i in sorted(need)}   # full resolution
+        plan['small'] = None if self.test else [self.pool.submit(_load_rgb, self.paths[int(i)], self.S, bool(f), self.rgba)
                                                 for i, f in zip(plan['img'], flips)]
         return plan
 
@@ -84,7 +83,7 @@ class FolderData:
             h = self.cache.get(i) if self.cache is not None else None
             if h is None:
                 fut = plan['full'].get(i)
-                x = (fut.result() if fut is not None else _load_rgb(self.paths[i])).unsqueeze(0).to(self.device)
+                x = (fut.result() if fut is not None else _load_rgb(self.paths[i], None, False, self.rgba)).unsqueeze(0).to(self.device)
                 with torch.no_grad():
                     h = self.hist_block(x)[0]
                 self.misses += 1

@@ -210,11 +210,11 @@ class SyntheticData:
     """Resident synthetic batches: images ~ U[0,1), target histograms = RGB-uv histograms of other random
     images (sum 1, all bins > 0) -- SURVEY.md section 8d.  Replaces the reference's DataLoader for benchmarks."""
 
-    def __init__(self, hist_block, batch_size, image_size, device, pool=4, seed=0):
+    def __init__(self, hist_block, batch_size, image_size, device, pool=4, seed=0, channels=3):
         g = torch.Generator(device='cpu').manual_seed(seed)
         self.batches = []
         for _ in range(pool):
-            img = torch.rand(batch_size, 3, image_size, image_size, generator=g).to(device)
+            img = torch.rand(batch_size, channels, image_size, image_size, generator=g).to(device)
             with torch.no_grad():
                 hist = hist_block(torch.rand(batch_size, 3, image_size, image_size, generator=g).to(device))
             self.batches.append({'images': img, 'histograms': hist})
@@ -317,8 +317,9 @@ class Trainer():
 
     def set_synthetic_data_src(self, pool=4, seed=None):
         seed = ddp.rank() if seed is None else seed
-        self.loader = SyntheticData(self.histBlock, self.batch_size, self.image_size, self.device, pool, seed)
-        self.loader_evaluate = SyntheticData(self.histBlock, 4, min(self.image_size, 150), self.device, 1, seed + 977)
+        ch = 4 if self.transparent else 3
+        self.loader = SyntheticData(self.histBlock, self.batch_size, self.image_size, self.device, pool, seed, ch)
+        self.loader_evaluate = SyntheticData(self.histBlock, 4, min(self.image_size, 150), self.device, 1, seed + 977, ch)
 
     def set_data_src(self, folder):
         from .data import FolderData

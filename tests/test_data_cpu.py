@@ -19,6 +19,11 @@ class FakeHist:
         return x.mean(dim=(2, 3)).view(1, 3, 1, 1).expand(1, 3, 4, 4) / 3.0
 
 
+class FakeHistAny(FakeHist):
+    def __call__(self, x):
+        return x[:, :3].mean(dim=(2, 3)).view(1, 3, 1, 1).expand(1, 3, 4, 4) / 3.0
+
+
 @pytest.fixture()
 def folder(tmp_path):
     from PIL import Image
@@ -59,8 +64,8 @@ def test_modes(folder):
         assert torch.allclose(batch['histograms'][k], FakeHist()(full)[0])
     with pytest.raises(FileNotFoundError):
         FolderData(folder + '/nothing_here', FakeHist(), 1, 16, dev)
-    with pytest.raises(NotImplementedError):
-        FolderData(folder, FakeHist(), 1, 16, dev, transparent=True)
+    rgba = next(FolderData(folder, FakeHistAny(), 2, 16, dev, transparent=True))
+    assert rgba['images'].shape == (2, 4, 16, 16) and float(rgba['images'][:, 3].min()) == 1.0   # opaque sources
 
 
 def test_resize_crop_flip_and_grid(folder, tmp_path):

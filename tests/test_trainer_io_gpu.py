@@ -61,3 +61,18 @@ def test_folder_source_checkpoint_and_evaluate(gpu_device, tmp_path):
     imgs = tr2.evaluate(num=7, num_image_tiles=2)
     assert imgs.shape == (4, 3, 32, 32) and float(imgs.min()) >= 0.0 and float(imgs.max()) <= 1.0
     assert (tmp_path / 'results' / 'io' / '7-ema.jpg').exists()
+
+
+def test_transparent_rgba_steps(gpu_device, tmp_path):
+    """transparent=True: 4-channel generator output / discriminator input (reference :374-376, 577); the histogram
+    takes the first three channels (RGBuvHistBlock.py:98-99)."""
+    from histoGAN import Trainer
+    tr = Trainer('rgba', str(tmp_path / 'r'), str(tmp_path / 'm'), 32, 2, transparent=True, batch_size=2, hist_bin=16,
+                 hist_insz=32, hist_resizing='interpolation')
+    tr.run_evaluate = tr.run_save = False
+    tr.set_synthetic_data_src()
+    tr.train(alpha=2)
+    tr.train(alpha=2)
+    assert np.isfinite(tr.d_loss) and np.isfinite(tr.g_loss) and np.isfinite(tr.h_loss)
+    assert tr.GAN.G.blocks[-1].to_rgb.conv.weight.shape[0] == 4 and tr.GAN.D.blocks[0].conv_res.weight.shape[1] == 4
+    assert tr.evaluate(num=None).shape[1] == 4
