@@ -842,6 +842,142 @@ __global__ __launch_bounds__(256) void k_hist_thr_bwd(const DevParams P, const f
     for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// RBF with a narrow kernel (the default sigma = 0.02 against a bin spacing of 6/63: exp(-d^2/sigma^2) is 1.4e-10 one bin
+// away): beyond R = ceil(5.26 sigma / spacing) bins the weights are < 1e-12 -- a pixel touches (2R+1)^2 bins per plane,
+// so the histogram is a scatter-add like thresholding (same fixed-point LDS grids), not a dense h x h product, and the
+// backward a (2R+1)^2 gather.  Used when R <= HG_RBF_RMAX; wider kernels take the MFMA path.
+constexpr int HG_RBF_RMAX = 2;
+
+// nearest bin of u (clamped) -- the centre of the (2R+1)-bin support
+__device__ __forceinline__ int rbf_center(const DevParams &P, float u, double inv_step) {
+  const double t = ((double)u - P.lo) * inv_step;
+  if (!(t > -1.0e6 && t < 1.0e6)) return t > 0.0 ? 2 * P.h : -P.h;
+  return (int)rint(t);
+}
+
+template <bool ALL3>
+__global__ __launch_bounds__(ALL3 ? 1024 : 256) void k_hist_rbf_fwd(const DevParams P, const float *__restrict__ x,
+                                                                    float *__restrict__ slabs, int per_block, int R) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem);   // [planes][h][h]
+  constexpr int NT = ALL3 ? 1024 : 256;
+  const int b = blockIdx.y, s = blockIdx.x, S = gridDim.x, h = P.h, hh = h * h;
+  const float *xb = x + (long long)b * P.sb;
+  const int n0 = s * per_block, n1 = min(P.npix, n0 + per_block);
+  float *slab = slabs + ((long long)(b * S + s) * P.P) * hh;
+  const double inv_step = P.step > 0.0 ? 1.0 / P.step : 0.0;
+  auto scatter = [&](unsigned long long *grid, float u, float v, float iy) __attribute__((always_inline)) {
+    const int ic = rbf_center(P, u, inv_step), jc = rbf_center(P, v, inv_step);
+    float ku[2 * HG_RBF_RMAX + 1], kv[2 * HG_RBF_RMAX + 1];
+#pragma unroll
+    for (int d = 0; d < 2 * HG_RBF_RMAX + 1; ++d) {
+      const int i = ic + d - R, j = jc + d - R;
+      ku[d] = (d <= 2 * R && i >= 0 && i < h) ? __fmul_rn(iy, kern_eval<HG_METHOD_RBF>(P, u, make_binc(P, i, false))) : 0.f;
+      kv[d] = (d <= 2 * R && j >= 0 && j < h) ? kern_eval<HG_METHOD_RBF>(P, v, make_binc(P, j, false)) : 0.f;
+    }
+#pragma unroll
+    for (int di = 0; di < 2 * HG_RBF_RMAX + 1; ++di) {
+      if (ku[di] == 0.f) continue;
+#pragma unroll
+      for (int dj = 0; dj < 2 * HG_RBF_RMAX + 1; ++dj) {
+        const float wgt = __fmul_rn(ku[di], kv[dj]);
+        const unsigned long long q = (unsigned long long)((double)wgt * kThrScale + 0.5);
+        if (q) atomicAdd(&grid[(ic + di - R) * h + (jc + dj - R)], q);
+      }
+    }
+  };
+  if constexpr (ALL3) {
+    for (int e = threadIdx.x; e < P.P * hh; e += NT) bins[e] = 0ull;
+    __syncthreads();
+    for (int n = n0 + threadIdx.x; n < n1; n += NT) {
+      float r, g, bl, a, bb, c, iy;
+      sample_rgb(P, xb, n, r, g, bl);
+      project(P, r, g, bl, a, bb, c, iy);
+      if (P.green) {
+        scatter(bins, -a, c, iy);
+      } else {
+        scatter(bins, a, bb, iy);
+        scatter(bins + hh, -a, c, iy);
+        scatter(bins + 2 * hh, -bb, -c, iy);
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < P.P * hh; e += NT) slab[e] = (float)((double)bins[e] * (1.0 / kThrScale));
+  } else {
+    for (int p = 0; p < 3; ++p) {
+      if (P.green && p != 1) continue;
+      for (int e = threadIdx.x; e < hh; e += NT) bins[e] = 0ull;
+      __syncthreads();
+      for (int n = n0 + threadIdx.x; n < n1; n += NT) {
+        float r, g, bl, a, bb, c, iy;
+        sample_rgb(P, xb, n, r, g, bl);
+        project(P, r, g, bl, a, bb, c, iy);
+        scatter(bins, p == 0 ? a : (p == 1 ? -a : -bb), p == 0 ? bb : (p == 1 ? c : -c), iy);
+      }
+      __syncthreads();
+      float *dst = slab + (long long)(P.green ? 0 : p) * hh;
+      for (int e = threadIdx.x; e < hh; e += NT) dst[e] = (float)((double)bins[e] * (1.0 / kThrScale));
+      __syncthreads();
+    }
+  }
+}
+
+// Backward of the truncated RBF histogram: the generic backward's two mat-vecs per plane restricted to the (2R+1)^2
+// support (kernel value and slope in fp64, as k_hist_bwd_generic).
+__global__ __launch_bounds__(256) void k_hist_rbf_bwd(const DevParams P, const float *__restrict__ x,
+                                                      const float *__restrict__ gh, float *__restrict__ gdst, int R) {
+  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x, h = P.h;
+  if (n >= P.npix) return;
+  const float *xb = x + (long long)b * P.sb;
+  float r, g, bl, a, bb, c, iy;
+  sample_rgb(P, xb, n, r, g, bl);
+  project(P, r, g, bl, a, bb, c, iy);
+  const double inv_step = P.step > 0.0 ? 1.0 / P.step : 0.0;
+  float gu[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f}, isum = 0.f;
+  for (int p = 0; p < 3; ++p) {
+    if (P.green && p != 1) continue;
+    const float *G = gh + ((long long)b * P.P + (P.green ? 0 : p)) * h * h;
+    const float u = p == 0 ? a : (p == 1 ? -a : -bb), v = p == 0 ? bb : (p == 1 ? c : -c);
+    const int ic = rbf_center(P, u, inv_step), jc = rbf_center(P, v, inv_step);
+    float ku[2 * HG_RBF_RMAX + 1], dku[2 * HG_RBF_RMAX + 1], kv[2 * HG_RBF_RMAX + 1], dkv[2 * HG_RBF_RMAX + 1];
+#pragma unroll
+    for (int d = 0; d < 2 * HG_RBF_RMAX + 1; ++d) {
+      const int i = ic + d - R, j = jc + d - R;
+      ku[d] = dku[d] = kv[d] = dkv[d] = 0.f;
+      if (d <= 2 * R && i >= 0 && i < h) kern_eval_d<HG_METHOD_RBF>(P, u, i, ku[d], dku[d]);
+      if (d <= 2 * R && j >= 0 && j < h) kern_eval_d<HG_METHOD_RBF>(P, v, j, kv[d], dkv[d]);
+    }
+    float Sx[2 * HG_RBF_RMAX + 1];
+#pragma unroll
+    for (int dj = 0; dj < 2 * HG_RBF_RMAX + 1; ++dj) Sx[dj] = 0.f;
+#pragma unroll
+    for (int di = 0; di < 2 * HG_RBF_RMAX + 1; ++di) {
+      const int i = ic + di - R;
+      if (di > 2 * R || i < 0 || i >= h) continue;
+      float T = 0.f;
+#pragma unroll
+      for (int dj = 0; dj < 2 * HG_RBF_RMAX + 1; ++dj) {
+        const int j = jc + dj - R;
+        if (dj > 2 * R || j < 0 || j >= h) continue;
+        const float Gij = G[i * h + j];
+        T = fmaf(Gij, kv[dj], T);
+        Sx[dj] = fmaf(Gij, ku[di], Sx[dj]);
+      }
+      gu[p] = fmaf(dku[di], T, gu[p]);
+      isum = fmaf(ku[di], T, isum);
+    }
+#pragma unroll
+    for (int dj = 0; dj < 2 * HG_RBF_RMAX + 1; ++dj) gv[p] = fmaf(dkv[dj], Sx[dj], gv[p]);
+  }
+  const float da = iy * (gu[0] - gu[1]), db = iy * (gv[0] - gu[2]), dc = iy * (gv[1] - gv[2]);
+  const float dIy = P.intensity ? isum : 0.f;
+  if (P.proj != HG_PROJ_RGBUV) store_pixel_grad_proj(P, xb, b, n, r, g, bl, iy, iy * gu[1], iy * gv[1], dIy, gdst);
+  else store_pixel_grad(P, xb, b, n, r, g, bl, iy, da, db, dc, dIy, gdst);
+  if (P.mode == HG_RESIZE_NONE)
+    for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
+}
+
 // Adjoint of the bilinear resize (deterministic gather) fused with the clamp mask.
 // grad_x[b][c][y][x] = mask(x) * sum_{Y,X} wy(Y->y) wx(X->x) gxs[b][c][Y][X]
 __global__ __launch_bounds__(256) void k_bilinear_adjoint(const DevParams P, const float *__restrict__ x,
@@ -941,6 +1077,19 @@ inline bool thr_scatter(const hg_hist_params *p) {
   return p->method == HG_METHOD_THRESHOLDING && (size_t)p->h * p->h * 8 <= 156 * 1024;
 }
 
+// RBF: support radius in bins beyond which exp(-d^2/sigma^2) < 1e-12; 0 = use the dense MFMA path
+inline int rbf_radius(const hg_hist_params *p) {
+  if (p->method != HG_METHOD_RBF || p->h < 2 || (size_t)p->h * p->h * 8 > 156 * 1024) return 0;
+  if (const char *e = getenv("HG_RBF_DENSE")) if (atoi(e)) return 0;     // A/B switch for measurements
+  const double step = (p->hi - p->lo) / (double)(p->h - 1);
+  if (!(step > 0.0)) return 0;
+  const double r = 5.2565 * p->sigma / step;          // sqrt(-ln 1e-12) = 5.2565
+  const int R = (int)ceil(r);
+  return (R >= 1 && R <= HG_RBF_RMAX) ? R : 0;
+}
+
+inline bool sparse_path(const hg_hist_params *p) { return thr_scatter(p) || rbf_radius(p) > 0; }
+
 Plan make_plan(const hg_hist_params *p) {
   Plan pl;
   pl.T = (p->h <= 32) ? 1 : 2;
@@ -953,7 +1102,7 @@ Plan make_plan(const hg_hist_params *p) {
   const long long wg_fixed = (long long)p->B * pl.nbd * pl.nbd;
   long long target = 512;
   // the scatter kernel keeps up to 98 KB of LDS grids: one workgroup per CU is all that fits, more only add slabs
-  if (thr_scatter(p)) target = 256;
+  if (sparse_path(p)) target = 256;
   if (const char *e = getenv("HG_FWD_WGS")) target = atoll(e) > 0 ? atoll(e) : target;  // tuning knob
   long long S = (target + wg_fixed - 1) / wg_fixed;
   const long long maxS = (npix + 255) / 256;
@@ -981,7 +1130,7 @@ Plan make_plan(const hg_hist_params *p) {
   pl.S_bwd = (int)Sb;
   pl.rounds = (int)rpw;
   // generic backward only (h > 64 or asymmetric boundary): Ghat in natural layout
-  pl.gh_bytes = ((p->lo != -p->hi) || pl.nbd != 1 || p->projection || thr_scatter(p)) ? ((size_t)p->B * n_per_img * sizeof(float) + 255) / 256 * 256 : 256;
+  pl.gh_bytes = ((p->lo != -p->hi) || pl.nbd != 1 || p->projection || sparse_path(p)) ? ((size_t)p->B * n_per_img * sizeof(float) + 255) / 256 * 256 : 256;
   pl.gxs_bytes = (p->resize_mode == HG_RESIZE_NONE) ? 0 : ((size_t)p->B * 3 * npix * sizeof(float) + 255) / 256 * 256;
   return pl;
 }
@@ -1098,16 +1247,25 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
   float *partials = (float *)workspace;
   float *slabs = (float *)((char *)workspace + pl.part_bytes);
   const bool sym = (p->lo == -p->hi);
-  if (thr_scatter(p)) {
+  if (sparse_path(p)) {
     const size_t one = (size_t)d.h * d.h * sizeof(unsigned long long);
     const bool all3 = one * d.P <= 150 * 1024;
     const size_t lds = all3 ? one * d.P : one;
-    auto kern = all3 ? k_hist_thr_fwd<true> : k_hist_thr_fwd<false>;
+    const int R = rbf_radius(p);
+    const void *kern = R ? (all3 ? (const void *)k_hist_rbf_fwd<true> : (const void *)k_hist_rbf_fwd<false>)
+                         : (all3 ? (const void *)k_hist_thr_fwd<true> : (const void *)k_hist_thr_fwd<false>);
     if (lds > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(kern, dim3(pl.S_fwd, d.B), dim3(all3 ? 1024 : 256), lds, st, d, x, slabs, 4 * pl.chunk);
+    const dim3 grid(pl.S_fwd, d.B), block(all3 ? 1024 : 256);
+    if (R) {
+      if (all3) hipLaunchKernelGGL(k_hist_rbf_fwd<true>, grid, block, lds, st, d, x, slabs, 4 * pl.chunk, R);
+      else hipLaunchKernelGGL(k_hist_rbf_fwd<false>, grid, block, lds, st, d, x, slabs, 4 * pl.chunk, R);
+    } else {
+      if (all3) hipLaunchKernelGGL(k_hist_thr_fwd<true>, grid, block, lds, st, d, x, slabs, 4 * pl.chunk);
+      else hipLaunchKernelGGL(k_hist_thr_fwd<false>, grid, block, lds, st, d, x, slabs, 4 * pl.chunk);
+    }
     HG_LAUNCH_CHECK();
   } else {
     int r = (pl.T == 1) ? launch_fwd_t<1>(d, pl, sym, x, slabs, st) : launch_fwd_t<2>(d, pl, sym, x, slabs, st);
@@ -1142,11 +1300,13 @@ int hg_rgbuv_hist_bwd(const hg_hist_params *p, const float *x, const float *grad
       if (e != hipSuccess) return (int)e;
     }
   }
-  if (thr_scatter(p)) {
+  if (sparse_path(p)) {
     float *gh = (float *)((char *)workspace + pl.gxs_bytes);
     hipLaunchKernelGGL(k_hist_ghat, dim3(d.B), dim3(1024), 0, st, grad_out, hist_out, sum_out, gh, d.P * d.h * d.h);
     HG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_hist_thr_bwd, dim3((d.npix + 255) / 256, d.B), dim3(256), 0, st, d, x, gh, gdst);
+    const int R = rbf_radius(p);
+    if (R) hipLaunchKernelGGL(k_hist_rbf_bwd, dim3((d.npix + 255) / 256, d.B), dim3(256), 0, st, d, x, gh, gdst, R);
+    else hipLaunchKernelGGL(k_hist_thr_bwd, dim3((d.npix + 255) / 256, d.B), dim3(256), 0, st, d, x, gh, gdst);
     HG_LAUNCH_CHECK();
   } else if (!generic) {
     int r = (pl.T == 1) ? launch_bwd_t<1>(d, pl, x, grad_out, hist_out, sum_out, gdst, st)

@@ -12,7 +12,7 @@ from histogan_amd.hist import HistConfig, rgbuv_hist  # noqa: E402
 dev = torch.device('cuda:0')
 B, S, h = 32, 256, 64
 for name, x in (('uniform', torch.rand(B, 3, S, S, device=dev)), ('constant colour', torch.full((B, 3, S, S), 0.4, device=dev))):
-    for method in ('thresholding', 'inverse-quadratic'):
+    for method in ('thresholding', 'RBF', 'inverse-quadratic'):
         cfg = HistConfig(h=h, insz=S, method=method, sigma=0.02)
         xg = x.clone().requires_grad_(True)
         out = rgbuv_hist(xg, cfg)
