@@ -51,7 +51,7 @@ def build(force=False, verbose=False):
         with open(STAMP) as f:
             if f.read().strip() == dig:
                 return LIB
-    objs = []
+    jobs = []
     for src in sources():
         obj = os.path.join(CSRC, os.path.basename(src)[:-4] + ('_' + TAG if TAG else '') + '.o')
         cmd = [hipcc(), f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-Wall',
@@ -59,8 +59,12 @@ def build(force=False, verbose=False):
         if verbose:
             cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
             print(' '.join(cmd), flush=True)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        jobs.append((cmd, obj))
+    # the translation units are independent: compile them side by side (hg_conv.hip alone is ~1 min)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+        list(pool.map(lambda j: subprocess.check_call(j[0]), jobs))
+    objs = [obj for _, obj in jobs]
     cmd = [hipcc(), f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs
     if verbose:
         print(' '.join(cmd), flush=True)

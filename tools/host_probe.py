@@ -18,9 +18,13 @@ ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--steps', type=int, default=12)
 ap.add_argument('--size', type=int, default=256)
 ap.add_argument('--cap', type=int, default=16)
+ap.add_argument('--fused', action='store_true', help='GeneratorBlock.FUSED = True (one launch per generator stage)')
 ap.add_argument('--profile-step', type=int, default=-1, help='cProfile this step index (host side)')
 a = ap.parse_args()
 from histoGAN import Trainer  # noqa: E402
+from histogan_amd.nets import GeneratorBlock  # noqa: E402
+
+GeneratorBlock.FUSED = a.fused
 
 tmp = tempfile.mkdtemp()
 tr = Trainer('p', tmp + '/r', tmp + '/m', a.size, a.cap, batch_size=a.batch, hist_insz=150)
