@@ -944,7 +944,13 @@ WgradPlan make_wgrad_plan(int B, int K, int N, int Hi, int Wi, int ksize, int st
   p.ktiles = (K + p.WK * p.MT - 1) / (p.WK * p.MT);
   p.ntiles = (N + p.WN * p.MT - 1) / (p.WN * p.MT);
   const int tiles = p.ktiles * p.ntiles;
-  int s = (512 + tiles - 1) / tiles;
+  // blocks to aim for: the tap-split 3x3 tiles are 12-wave blocks of which one fits a CU -> one round of 256
+#ifdef HG_WGRAD_TARGET
+  const int target = HG_WGRAD_TARGET;
+#else
+  const int target = (ksize == 3 && p.MT == 32 && HG_WGRAD_TAPSPLIT) ? 256 : 512;
+#endif
+  int s = (target + tiles - 1) / tiles;
   if (s > p.nchunks) s = p.nchunks;
   if (s < 1) s = 1;
   p.splits = s;
