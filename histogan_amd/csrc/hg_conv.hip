@@ -41,7 +41,7 @@
 #define HG_WGRAD_TAPSPLIT 2   // k_wgrad 2x2-tile blocks: the three kernel rows on three waves (12 waves, 3 per SIMD)
 #endif
 #ifndef HG_CONV_BIGTILE_SPLITK
-#define HG_CONV_BIGTILE_SPLITK 1
+#define HG_CONV_BIGTILE_SPLITK 2
 #endif     // input channels per K chunk of the stride-1 tiles (64x64 tile: twice that); 2/4/8 measure within 3 %
 #endif
 
@@ -792,7 +792,7 @@ struct Taps {
 };
 
 // tile shape + K split of one k_conv launch
-enum ConvTile { TILE_16x256, TILE_32x256, TILE_64x256, TILE_128x128, TILE_64x64 };
+enum ConvTile { TILE_16x256, TILE_32x256, TILE_64x256, TILE_128x128, TILE_128x128_SM, TILE_64x64 };
 struct ConvPlan {
   ConvTile tile;
   int ksplit;
@@ -825,6 +825,20 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
     }
 #endif
   }
+#if HG_CONV_BIGTILE_SPLITK > 1
+  // 4x4 maps (8 images per 128-pixel tile): the small-map instantiation of the 128x128 tile (larger halo bound)
+  if (N > 64 && Wc == 4 && Hc == 4 && big_split && have_ws && os == 1 && IS == 1) {
+    const long long nb = blocks(128, 128);
+    const int nch = (K + HG_CONV_KC - 1) / HG_CONV_KC;
+    if (nb >= 32 && nch >= 32) {
+      int ks = (int)((512 + nb - 1) / nb);
+      if (ks > nch / 8) ks = nch / 8;
+      if (ks > 16) ks = 16;
+      if (ks < 1) ks = 1;
+      p.tile = TILE_128x128_SM; p.ksplit = ks; return p;
+    }
+  }
+#endif
   p.tile = TILE_64x64;
   // pixel tiles of the 64x64 shape: images are grouped when the map is smaller than the tile
   const int tw = Wc <= 2 && IS == 1 ? 2 : (Wc <= 4 ? 4 : (Wc <= 8 ? 8 : (Wc <= 16 ? 16 : 32)));
@@ -902,6 +916,9 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
     case TILE_32x256: return launch_conv<1, 4, 1, 2, TAPS, KC, IS>(a, tp, 1, true, st);
     case TILE_64x256: return launch_conv<1, 4, 2, 2, TAPS, KC, IS>(a, tp, 1, true, st);
     case TILE_128x128: return launch_conv<2, 2, 2, 2, TAPS, KC, IS>(a, tp, p.ksplit, true, st);
+    case TILE_128x128_SM:
+      if constexpr (IS == 1) return launch_conv<2, 2, 2, 2, TAPS, KC, IS, true>(a, tp, p.ksplit, true, st);
+      else return HG_EUNSUPPORTED;
     default: return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, IS == 1>(a, tp, p.ksplit, true, st);
   }
 }

@@ -22,6 +22,8 @@ CASES = [
     (1, 64, 64, 8, 8, 3), (1, 68, 100, 8, 8, 3), (1, 66, 70, 8, 8, 3), (2, 128, 96, 4, 4, 3),
     # few pixels, many channels: the 128x128 tile with a K split (forward 132->500, data gradient 500->132 ... both > 64)
     (16, 132, 500, 8, 8, 3), (16, 256, 260, 8, 8, 3), (6, 192, 640, 12, 12, 3),
+    # 4x4 maps, many channels: the small-map instantiation of the 128x128 tile (8 images per pixel tile) + K split
+    (64, 132, 1000, 4, 4, 3), (40, 520, 136, 4, 4, 3),
 ]
 
 
