@@ -76,3 +76,27 @@ def test_transparent_rgba_steps(gpu_device, tmp_path):
     assert np.isfinite(tr.d_loss) and np.isfinite(tr.g_loss) and np.isfinite(tr.h_loss)
     assert tr.GAN.G.blocks[-1].to_rgb.conv.weight.shape[0] == 4 and tr.GAN.D.blocks[0].conv_res.weight.shape[1] == 4
     assert tr.evaluate(num=None).shape[1] == 4
+
+
+def test_nan_recovery_raises_nanexception(gpu_device, tmp_path):
+    """Reference error convention (histoGAN/histoGAN.py:1002-1010): a NaN loss reloads the last checkpoint and raises
+    NanException from train()."""
+    from histoGAN import NanException, Trainer
+    tr = Trainer('nan', str(tmp_path / 'r'), str(tmp_path / 'm'), 32, 2, batch_size=2, hist_bin=16, hist_insz=32,
+                 hist_resizing='interpolation', save_every=1000)
+    tr.run_evaluate = False
+    tr.set_synthetic_data_src()
+    tr.train(alpha=2)                                    # step 0 writes checkpoint 0
+    good = {k: v.clone() for k, v in tr.GAN.state_dict().items()}
+    with torch.no_grad():
+        tr.GAN.D.to_logit.weight.fill_(float('nan'))
+    from histogan_amd.conv import weights_changed
+    weights_changed()
+    with pytest.raises(NanException):
+        tr.train(alpha=2)
+    # the checkpoint was reloaded: finite weights again (those of step 0's save), training continues
+    assert all(torch.isfinite(v).all() for v in tr.GAN.state_dict().values())
+    assert tr.steps == 0
+    tr.train(alpha=2)
+    assert np.isfinite(tr.d_loss) and np.isfinite(tr.g_loss)
+    del good
