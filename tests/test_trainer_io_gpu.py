@@ -100,3 +100,19 @@ def test_nan_recovery_raises_nanexception(gpu_device, tmp_path):
     tr.train(alpha=2)
     assert np.isfinite(tr.d_loss) and np.isfinite(tr.g_loss)
     del good
+
+
+def test_gradient_accumulation_steps(gpu_device, tmp_path):
+    """gradient_accumulate_every = 2 with mixed_prob = 0 (reference :889-932: losses divided by the count, gradients
+    accumulated over the micro-batches before one optimizer step)."""
+    from histoGAN import Trainer
+    kw = dict(batch_size=2, hist_bin=16, hist_insz=32, hist_resizing='interpolation', mixed_prob=0.0)
+    tr = Trainer('acc', str(tmp_path / 'r'), str(tmp_path / 'm'), 32, 2, gradient_accumulate_every=2, **kw)
+    tr.run_evaluate = tr.run_save = False
+    tr.set_synthetic_data_src()
+    for _ in range(3):
+        tr.train(alpha=2)
+    assert tr.steps == 3 and np.isfinite(tr.d_loss) and np.isfinite(tr.g_loss) and np.isfinite(tr.h_loss)
+    # every parameter of G / S / H / D received a finite gradient through the flat buffers
+    for flat in (tr.GAN._flat_g, tr.GAN._flat_d):
+        assert torch.isfinite(flat.grad).all() and float(flat.grad.abs().sum()) > 0
