@@ -315,12 +315,54 @@ class ImageLinearAttention(nn.Module):
         return self.to_out(out.reshape(b, -1, h, w))
 
 
+class PermuteToFrom(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+    def forward(self, x):
+        out, loss = self.fn(x.permute(0, 2, 3, 1))
+        return out.permute(0, 3, 1, 2), loss
+
+
+class VectorQuantize(nn.Module):
+    """Feature quantisation of the discriminator's optional `fq_layers` (reference histoGAN/histoGAN.py:598-600 takes it
+    from the third-party `vector_quantize_pytorch`, absent from the reference tree and unpinned: restated from the
+    published algorithm -- VQ-VAE codebook with exponential-moving-average updates, straight-through estimator and
+    commitment loss -- PARITY UNPINNED).  Buffers `embed` (dim, n_embed), `cluster_size`, `embed_avg` as upstream.
+    Nearest-code search and the EMA statistics are two small GEMMs (rocBLAS); under data parallelism every rank
+    updates its own codebook from its own shard (the reference is single-GPU)."""
+
+    def __init__(self, dim, n_embed, decay=0.8, commitment=1., eps=1e-5):
+        super().__init__()
+        self.dim, self.n_embed, self.decay, self.commitment, self.eps = dim, n_embed, decay, commitment, eps
+        embed = torch.randn(dim, n_embed)
+        self.register_buffer('embed', embed)
+        self.register_buffer('cluster_size', torch.zeros(n_embed))
+        self.register_buffer('embed_avg', embed.clone())
+
+    def forward(self, input):
+        flatten = input.reshape(-1, self.dim)
+        dist = flatten.pow(2).sum(1, keepdim=True) - 2 * flatten @ self.embed + self.embed.pow(2).sum(0, keepdim=True)
+        embed_ind = (-dist).max(1)[1]
+        quantize = F.embedding(embed_ind.view(*input.shape[:-1]), self.embed.transpose(0, 1))
+        if self.training:
+            with torch.no_grad():
+                onehot = F.one_hot(embed_ind, self.n_embed).type(input.dtype)
+                self.cluster_size.mul_(self.decay).add_(onehot.sum(0), alpha=1 - self.decay)
+                self.embed_avg.mul_(self.decay).add_(flatten.detach().transpose(0, 1) @ onehot, alpha=1 - self.decay)
+                n = self.cluster_size.sum()
+                cluster_size = (self.cluster_size + self.eps) / (n + self.n_embed * self.eps) * n     # Laplace smoothing
+                self.embed.copy_(self.embed_avg / cluster_size.unsqueeze(0))
+        loss = F.mse_loss(quantize.detach(), input) * self.commitment
+        quantize = input + (quantize - input).detach()
+        return quantize, loss
+
+
 class Discriminator(nn.Module):
     def __init__(self, image_size, network_capacity=16, fq_layers=[], fq_dict_size=256, attn_layers=[],
                  transparent=False):
         super().__init__()
-        if list(fq_layers):
-            raise NotImplementedError('fq_layers need vector_quantize_pytorch (third-party, absent): not implemented')
         num_layers = int(log2(image_size) - 1)
         num_init_filters = 3 if not transparent else 4
         filters = [num_init_filters] + [network_capacity * (2 ** i) for i in range(num_layers + 1)]
@@ -331,15 +373,21 @@ class Discriminator(nn.Module):
         self.attn_blocks = nn.ModuleList([
             nn.Sequential(*[Residual(Rezero(ImageLinearAttention(o))) for _ in range(2)])
             if ind + 1 in attn_layers else None for ind, (i, o) in enumerate(chan_in_out)])
-        self.quantize_blocks = nn.ModuleList([None for _ in chan_in_out])
+        fq_layers = [int(a) for a in fq_layers]
+        self.quantize_blocks = nn.ModuleList([
+            PermuteToFrom(VectorQuantize(o, fq_dict_size)) if ind + 1 in fq_layers else None
+            for ind, (i, o) in enumerate(chan_in_out)])
         self.flatten = Flatten()
         self.to_logit = nn.Linear(2 * 2 * filters[-1], 1)
 
     def forward(self, x):
         quantize_loss = torch.zeros(1).to(x)
-        for block, attn_block in zip(self.blocks, self.attn_blocks):
+        for block, attn_block, q_block in zip(self.blocks, self.attn_blocks, self.quantize_blocks):
             x = block(x)
             if attn_block is not None:
                 x = attn_block(x)
+            if q_block is not None:
+                x, loss = q_block(x)
+                quantize_loss = quantize_loss + loss
         x = self.to_logit(self.flatten(x))
         return x.squeeze(), quantize_loss

@@ -303,10 +303,15 @@ class recoloringTrainer():
             noise = self.rng.image_noise(batch_size, image_size)
             with torch.no_grad():       # the reference detaches this output; no graph is needed
                 generated_images = self._recolor(image_batch, hist_batch, noise)
-            both_output, both_q_loss = Disc(torch.cat((generated_images, image_batch), dim=0))
-            fake_output, real_output = both_output[:batch_size], both_output[batch_size:]
+            if any(q is not None for q in Disc.quantize_blocks):      # batch-dependent codebook: two passes
+                fake_output, fake_q_loss = Disc(generated_images)
+                real_output, real_q_loss = Disc(image_batch)
+                quantize_loss = (fake_q_loss + real_q_loss).mean()
+            else:
+                both_output, both_q_loss = Disc(torch.cat((generated_images, image_batch), dim=0))
+                fake_output, real_output = both_output[:batch_size], both_output[batch_size:]
+                quantize_loss = both_q_loss.mean()
             divergence = (F.relu(1 + real_output) + F.relu(1 - fake_output)).mean()
-            quantize_loss = both_q_loss.mean()
             q_val = quantize_loss.detach()
             disc_loss = divergence + quantize_loss
             if apply_gradient_penalty:

@@ -359,6 +359,7 @@ class Trainer():
         acc = self.gradient_accumulate_every
         apply_gradient_penalty = self.steps % 4 == 0
         apply_path_penalty = self.steps % 32 == 0
+        has_vq = any(q is not None for q in Disc.quantize_blocks)
         # DiffAugment of everything the discriminator sees (reference :873-878, 905-908, 950-951)
         aug = (lambda im, detach=False: GAN.D_aug.augment(im, prob=self.aug_prob, types=self.aug_types, detach=detach)
                ) if self.aug_prob > 0.0 else (lambda im, detach=False: im)
@@ -378,9 +379,13 @@ class Trainer():
                 generated_images = GAN.G(w_styles, h_w_space, noise)
             # one discriminator pass over [fake; real] (samples are independent: same values as two passes,
             # :911-912, but twice the pixels per launch on the small maps)
-            both_output, both_q_loss = Disc(torch.cat((aug(generated_images, True), aug(image_batch)), dim=0))
-            fake_output, real_output = both_output[:batch_size], both_output[batch_size:]
-            fake_q_loss = real_q_loss = both_q_loss * 0.5
+            if has_vq:   # the codebook's moving averages and its loss depend on the batch: two passes, reference order
+                fake_output, fake_q_loss = Disc(aug(generated_images, True))
+                real_output, real_q_loss = Disc(aug(image_batch))
+            else:
+                both_output, both_q_loss = Disc(torch.cat((aug(generated_images, True), aug(image_batch)), dim=0))
+                fake_output, real_output = both_output[:batch_size], both_output[batch_size:]
+                fake_q_loss = real_q_loss = both_q_loss * 0.5
             divergence = (F.relu(1 + real_output) + F.relu(1 - fake_output)).mean()
             quantize_loss = (fake_q_loss + real_q_loss).mean()
             q_val = quantize_loss.detach()

@@ -89,6 +89,16 @@ def image_linear_attention(sd, pre, x, key_dim=64, heads=8):
     return F.conv2d(out, sd[pre + 'to_out.weight'], sd[pre + 'to_out.bias'])
 
 
+def vector_quantize(embed, x, commitment=1.0):
+    """vector_quantize_pytorch.VectorQuantize in eval mode (no EMA update) on a channels-last tensor: nearest code,
+    straight-through output, commitment loss (third-party, unpinned: restated -- PARITY UNPINNED)."""
+    flat = x.reshape(-1, embed.shape[0])
+    dist = flat.pow(2).sum(1, keepdim=True) - 2 * flat @ embed + embed.pow(2).sum(0, keepdim=True)
+    ind = (-dist).max(1)[1]
+    q = F.embedding(ind.view(*x.shape[:-1]), embed.t())
+    return x + (q - x).detach(), F.mse_loss(q.detach(), x) * commitment
+
+
 def discriminator(sd, x, num_blocks):
     for i in range(num_blocks):
         p = f'blocks.{i}.'

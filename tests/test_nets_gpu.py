@@ -392,3 +392,39 @@ def test_train_steps_with_attention(gpu_device, tmp_path):
         tr.train(alpha=2)
     assert np.isfinite(tr.d_loss) and np.isfinite(tr.g_loss) and np.isfinite(tr.last_gp_loss)
     assert any('attn_blocks.0.0.fn.fn.to_q.weight' in k for k in tr.GAN.state_dict())
+
+
+def test_vector_quantize_layers(gpu_device, tmp_path):
+    """fq_layers (reference :598-600): nearest-code output, straight-through gradient and commitment loss against the
+    oracle restatement; EMA codebook statistics move in training mode only; trainer steps with fq_layers."""
+    from histogan_amd.nets import Discriminator, VectorQuantize
+    from oracle import histogan_nets as N
+    torch.manual_seed(2)
+    vq = VectorQuantize(8, 32).to(gpu_device)
+    x = torch.randn(3, 5, 7, 8, device=gpu_device, requires_grad=True)          # channels-last
+    vq.eval()
+    e0 = vq.embed.clone()
+    q, loss = vq(x)
+    assert torch.equal(vq.embed, e0)                                            # no update in eval mode
+    xc = x.detach().cpu().requires_grad_(True)
+    qr, lr = N.vector_quantize(e0.cpu(), xc)
+    assert relmax(q.detach().cpu().numpy(), qr.detach().numpy()) <= 1e-6 and abs(float(loss) - float(lr)) <= 1e-6
+    g, = torch.autograd.grad(q.sum() + loss, x)
+    gr, = torch.autograd.grad(qr.sum() + lr, xc)
+    assert relmax(g.cpu().numpy(), gr.numpy()) <= 1e-5
+    codes = q.detach().reshape(-1, 8)
+    assert float((codes[:, None, :] - e0.t()[None]).abs().sum(-1).min(1)[0].max()) <= 1e-5     # every output IS a code
+    vq.train()
+    vq(x)
+    assert not torch.equal(vq.embed, e0) and float(vq.cluster_size.sum()) > 0
+    D = Discriminator(32, 2, fq_layers=[2], fq_dict_size=16).to(gpu_device)
+    assert {'quantize_blocks.1.fn.embed', 'quantize_blocks.1.fn.cluster_size', 'quantize_blocks.1.fn.embed_avg'} <= set(D.state_dict())
+    logits, ql = D(torch.rand(2, 3, 32, 32, device=gpu_device))
+    assert logits.shape == (2,) and float(ql) > 0
+    from histoGAN import Trainer
+    tr = Trainer('vq', tmp_path / 'r', tmp_path / 'm', 32, 2, batch_size=2, hist_bin=16, hist_insz=32,
+                 hist_resizing='interpolation', fq_layers=[1, 2], fq_dict_size=16)
+    tr.run_evaluate = tr.run_save = False
+    tr.set_synthetic_data_src()
+    tr.train(alpha=2); tr.train(alpha=2)
+    assert np.isfinite(tr.d_loss) and np.isfinite(tr.g_loss) and tr.q_loss > 0
