@@ -49,15 +49,16 @@ def hist_workload(args, dev, rank, world):
         hist = rgbuv_hist(x, cfg)
         hellinger_loss(target, hist, alpha=2.0).backward()
 
-    def time_kernels(iters):
+    def time_kernels(iters, method=None):
         """HIP events (on the stream the kernels are launched on) around the forward and the backward
         C-ABI calls, buffers preallocated: pure device time of [k_hist_fwd + reduce + normalize] and
-        of [k_hist_bwd] -- the small kernels are <5 % of either (profiles/)."""
+        of [k_hist_bwd] -- the small kernels are <5 % of either (profiles/).  method: another kernel method on the
+        same input (the scatter-add path of 'thresholding')."""
         import ctypes
         from histogan_amd import hist as HH
         from histogan_amd._lib import lib, check
         xd = x.detach()
-        p, keep = HH._make_params(xd, cfg)
+        p, keep = HH._make_params(xd, cfg if method is None else HistConfig(h=h, insz=S, method=method, sigma=0.02))
         fb, bb = HH._ws_bytes(p)
         out = torch.empty(B, 3, h, h, device=dev)
         sums = torch.empty(B, device=dev)
@@ -326,6 +327,12 @@ def main():
                  'launch_ms': t_bwd * 1e3,
                  'fwd': {'kernel': 'k_hist_fwd', 'achieved': work['flops_fwd'] / t_fwd / 1e12,
                          'frac': work['flops_fwd'] / t_fwd / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': t_fwd * 1e3}}
+    # the HBM-side method of the same block: thresholding on the scatter-add / gather kernels
+    tt_f, tt_b = time_kernels(min(max(args.steps, 5), 20), 'thresholding')
+    thr_gbps = (work['bytes_fwd'] + work['bytes_bwd']) / (tt_f + tt_b) / 1e9
+    hist_roof['thresholding'] = {'kernels': 'k_hist_thr_fwd + reduce + normalize / k_hist_ghat + k_hist_thr_bwd', 'bound': 'hbm',
+                                 'fwd_ms': tt_f * 1e3, 'bwd_ms': tt_b * 1e3, 'achieved': thr_gbps, 'peak': HBM_PEAK_GBPS,
+                                 'unit': 'GB/s', 'frac': thr_gbps / HBM_PEAK_GBPS}
     if args.workload in ('train', 'rehistogan'):
         ct = conv_kernel_times(dev, args.batch)
         fl, tf, td, tw = ct[(256, 128, 64)]
