@@ -1,6 +1,5 @@
 """GPU parity of the fp32-MFMA implicit-GEMM convolutions (include/hg_conv.h) against torch's fp64
 convolution of the same op (output, data gradient, weight gradient, bias gradient), through the C ABI."""
-import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F

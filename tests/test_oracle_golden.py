@@ -1,5 +1,4 @@
 """Pin the oracle (oracle/rgbuv_hist.py) to golden vectors produced by the unmodified reference."""
-import numpy as np
 import pytest
 import torch
 

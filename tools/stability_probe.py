@@ -1,6 +1,7 @@
+"""Numerical stability run: 160 HistoGAN and 80 ReHistoGAN train steps at 64x64 / capacity 8 on synthetic data (losses every 20 steps).
+    python tools/stability_probe.py"""
 import sys, os, tempfile
-sys.path.insert(0, os.getcwd())
-import torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from histoGAN import Trainer
 from ReHistoGAN import recoloringTrainer
 tmp = tempfile.mkdtemp()
