@@ -11,6 +11,7 @@ gradient penalty (histoGAN/histoGAN.py:156-163) needs the second order.
 """
 import contextlib
 import ctypes
+import os
 
 import torch
 
@@ -208,17 +209,88 @@ def conv_dgrad_packed(g, wt, N, H, W, ksize, stride=1, iscale=None, oscale=None)
     return gin
 
 
-def conv_wgrad(x, gout, ksize, stride=1, iscale=None, gscale=None):
-    """gw[n,k,dy,dx] = sum_{b,y,x} gscale[b,n] gout[b,n,y,x] * iscale[b,k] x[b,k,y*s+dy-p,x*s+dx-p]."""
+def conv_wgrad(x, gout, ksize, stride=1, iscale=None, gscale=None, out=None):
+    """gw[n,k,dy,dx] = sum_{b,y,x} gscale[b,n] gout[b,n,y,x] * iscale[b,k] x[b,k,y*s+dy-p,x*s+dx-p].
+    out: optional contiguous (N,K,k,k) tensor to write (e.g. the weight's slice of a flat gradient buffer)."""
     B, K, H, W = x.shape
     N = gout.shape[1]
     with torch.cuda.device(x.device):
         nbytes = lib.hg_conv2d_wgrad_workspace_bytes(B, K, N, H, W, ksize, stride)
         ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=x.device)
-        gw = torch.empty((N, K, ksize, ksize), dtype=torch.float32, device=x.device)
+        gw = out if out is not None else torch.empty((N, K, ksize, ksize), dtype=torch.float32, device=x.device)
         check(lib.hg_conv2d_wgrad(x.data_ptr(), gout.data_ptr(), gw.data_ptr(), _ptr(iscale), _ptr(gscale),
                                   B, K, N, H, W, ksize, stride, ws.data_ptr(), ws.numel(), _st(x)), 'hg_conv2d_wgrad')
     return gw
+
+
+
+# ---- weight gradients straight into the optimizer's flat gradient buffer, on a side stream ----------------------
+# In a plain backward pass (no graph being built) the weight gradient of a registered convolution weight is not
+# handed to autograd at all: k_wgrad writes it into the weight's slice of the flat gradient buffer (optim.FlatParams)
+# on a SIDE stream.  (i) no per-parameter copy into the flat buffer afterwards; (ii) the MFMA-bound weight-gradient
+# kernel runs beside the HBM-bound elementwise kernels that follow the convolution in the backward pass (LeakyReLU /
+# modulation / demodulation gradients, residual adds): measured 50 % of their time hidden (tools/overlap_probe.py).
+# All direct writes go through the one side stream, in order, so a second contribution to the same weight in the same
+# step (gradient accumulation, the gradient penalty's second-order term, the path-length pass) is simply added there;
+# FlatParams.gather() makes the main stream wait for the side stream before anything reads the buffer.
+SIDE_WGRAD = os.environ.get('HG_WGRAD_STREAM', '1') != '0'
+_slots = {}          # (data_ptr, shape) of a registered weight -> (offset, numel, weakref to the owner FlatParams)
+_side_streams = {}   # device index -> torch.cuda.Stream
+
+
+def register_grad_slots(flat):
+    """Called by FlatParams: convolution weights (4-d parameters) of `flat` may receive their gradient directly.
+    Only a weak reference to the owner is kept (a dead owner's entries are dropped on lookup)."""
+    import weakref
+    ref = weakref.ref(flat)
+    off = 0
+    for p in flat.params:
+        n = p.numel()
+        if p.dim() == 4 and flat.grad is not None:
+            _slots[(p.data_ptr(), tuple(p.shape))] = (off, n, ref)
+        off += n
+
+
+def side_stream(device):
+    st = _side_streams.get(device.index)
+    if st is None:
+        st = _side_streams[device.index] = torch.cuda.Stream(device=device)
+    return st
+
+
+def _direct_wgrad(w, x, g, stride):
+    """Weight gradient of conv(x, w) for upstream gradient g into w's flat-buffer slot; False if w has no slot (or
+    a graph is being recorded): the caller then returns the gradient to autograd as usual."""
+    if not SIDE_WGRAD or torch.is_grad_enabled():
+        return False
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = _slots.get(key)
+    if ent is None:
+        return False
+    off, n, ref = ent
+    flat = ref()
+    if flat is None:
+        del _slots[key]
+        return False
+    if not getattr(flat, 'direct_ok', False):       # between zero_grad() and gather() only
+        return False
+    slot = flat.grad[off:off + n].view(w.shape)
+    xc, gc = _f32c(x), _f32c(g)
+    if _batch_pieces(xc, w, stride) != 1:
+        return False
+    main = torch.cuda.current_stream(x.device)
+    side = side_stream(x.device)
+    side.wait_event(main.record_event())             # g (and x) are ready on the main stream
+    skey = slot.data_ptr()
+    with torch.cuda.stream(side):
+        if skey in flat.direct_written:
+            slot.add_(conv_wgrad(xc, gc, w.shape[2], stride))
+        else:
+            conv_wgrad(xc, gc, w.shape[2], stride, out=slot)
+            flat.direct_written.add(skey)
+    xc.record_stream(side)                           # the caching allocator must not recycle them under the kernel
+    gc.record_stream(side)
+    return True
 
 
 class _Conv(torch.autograd.Function):
@@ -244,7 +316,7 @@ class _Conv(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _ConvDgrad.apply(g, w, x.shape[2], x.shape[3], ctx.stride)
         if not _skip_wgrad:
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] and not _direct_wgrad(w, x, g, ctx.stride):
                 gw = _ConvWgrad.apply(g, x, w.shape[2], ctx.stride)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 if torch.is_grad_enabled():     # higher-order pass: keep the sum on the autograd tape
@@ -274,7 +346,7 @@ class _ConvDgrad(torch.autograd.Function):
         gg = gw = None
         if ctx.needs_input_grad[0]:
             gg = _Conv.apply(ggx, w, None, ctx.stride)
-        if ctx.needs_input_grad[1] and not _skip_wgrad:
+        if ctx.needs_input_grad[1] and not _skip_wgrad and not _direct_wgrad(w, ggx, g, ctx.stride):
             gw = _ConvWgrad.apply(g, ggx, w.shape[2], ctx.stride)
         return gg, gw, None, None, None
 
@@ -338,7 +410,7 @@ class _ConvLrelu(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _ConvDgrad.apply(gm, w, x.shape[2], x.shape[3], ctx.stride)
         if not _skip_wgrad:
-            if ctx.needs_input_grad[1]:
+            if ctx.needs_input_grad[1] and not _direct_wgrad(w, x, gm, ctx.stride):
                 gw = _ConvWgrad.apply(gm, x, w.shape[2], ctx.stride)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 if torch.is_grad_enabled():

@@ -43,6 +43,12 @@ class FlatParams:
             if with_grad:
                 p.grad = self.grad[off:off + n].view(p.shape)
             off += n
+        # convolution weights may get their gradient written straight into self.grad (conv._direct_wgrad)
+        self.direct_ok = False
+        self.direct_written = set()
+        if with_grad:
+            from .conv import register_grad_slots
+            register_grad_slots(self)
 
     def zero_grad(self):
         """Drop the parameter gradients.  With `.grad = None` autograd's AccumulateGrad hands over the incoming gradient
@@ -51,19 +57,28 @@ class FlatParams:
         for p in self.params:
             p.grad = None
         self._gathered = False
+        self.direct_written = set()
+        self.direct_ok = True
 
     def gather(self):
         """Make `self.grad` (and every `p.grad`, re-pointed to its slice) hold the gradients of the last backward
         passes; parameters that received none get zeros.  Idempotent."""
         if getattr(self, '_gathered', True):
             return
-        dst, src, missing = [], [], []
+        self.direct_ok = False
+        if self.direct_written:      # weight gradients written on the side stream: order them before any reader
+            from .conv import side_stream
+            torch.cuda.current_stream(self.grad.device).wait_stream(side_stream(self.grad.device))
+        dst, src, missing, both = [], [], [], []
         off = 0
         base = self.grad.data_ptr()
         for p in self.params:
             n = p.numel()
             v = self.grad[off:off + n].view(p.shape)
-            if p.grad is None:
+            if base + 4 * off in self.direct_written:
+                if p.grad is not None and p.grad.data_ptr() != base + 4 * off:
+                    both.append((v, p.grad))       # autograd ALSO delivered a part (a pass that recorded a graph)
+            elif p.grad is None:
                 missing.append(v)
             elif p.grad.data_ptr() != base + 4 * off:
                 dst.append(v)
@@ -74,6 +89,8 @@ class FlatParams:
             torch._foreach_copy_(dst, src)
         if missing:
             torch._foreach_zero_(missing)
+        if both:
+            torch._foreach_add_([v for v, _ in both], [g for _, g in both])
         self._gathered = True
 
 
