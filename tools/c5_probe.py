@@ -3,7 +3,7 @@
 (attention after discriminator block 1 at 1024^2 means q/k/v of 512 channels on 512^2 maps: 8.6 GB each for the
 16-image [fake; real] pass -- out of memory at 288 GB together with the gradient penalty's double backward.)"""
 import sys, os, tempfile, time, json
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 ATTN = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '3,4').split(',') if v]
 from histoGAN import Trainer
