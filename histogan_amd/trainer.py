@@ -16,6 +16,7 @@ NaN recovery) -- restructured for the hardware:
   draws (`torch.randn(...).cuda()`, :166-189) for parity tests.
 """
 import json
+import os
 from math import floor, log2
 from pathlib import Path
 from random import random
@@ -36,6 +37,7 @@ from .optim import DiffGrad, FlatParams, ema_update
 
 EPS = 1e-8
 EXTS = ['jpg', 'png']
+G_OVERLAP = os.environ.get('HG_G_OVERLAP', '1') != '0'   # G-phase generator forward on a second stream beside the D phase
 
 
 class NanException(Exception):
@@ -329,6 +331,11 @@ class Trainer():
                                           transparent=self.transparent, seed=977 + ddp.rank(), test=True)
 
     # ------------------------------------------------------------------------------------------
+    def _g_stream(self):
+        if getattr(self, '_gstream', None) is None:
+            self._gstream = torch.cuda.Stream(device=self.device)
+        return self._gstream
+
     def _w_and_hw(self, style, hist_batch):
         GAN = self.GAN
         w_space = latent_to_w(GAN.S, style)
@@ -364,6 +371,25 @@ class Trainer():
         aug = (lambda im, detach=False: GAN.D_aug.augment(im, prob=self.aug_prob, types=self.aug_types, detach=detach)
                ) if self.aug_prob > 0.0 else (lambda im, detach=False: im)
 
+        def g_forward():
+            """latents, noise, target histograms and the generator forward of the G phase (reference :937-949)"""
+            style = get_latents_fn(batch_size, num_layers - 2, latent_dim)
+            noise = self.rng.image_noise(batch_size, image_size)
+            hist_batch = next(self.loader)['histograms'].to(dev)
+            w_styles, h_w_space = self._w_and_hw(style, hist_batch)
+            return noise, hist_batch, w_styles, h_w_space, GAN.G(w_styles, h_w_space, noise)
+
+        # (single-GPU runs only: under data parallelism the D-gradient all-reduce hides behind the G-phase forward instead)
+        overlap_g = G_OVERLAP and acc == 1 and not ddp.is_dist()
+        if overlap_g and not getattr(self, '_warn_off', False):
+            # parameters live on the default stream, part of the graph now runs on another one: the engine's stream
+            # hand-over is intended
+            fn = getattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch', None)
+            if fn is not None:
+                fn(False)
+            self._warn_off = True
+        early = None
+
         # ---- discriminator phase (reference :889-932)
         GAN.D_opt.zero_grad()
         for i in range(acc):
@@ -379,6 +405,16 @@ class Trainer():
                 generated_images = GAN.G(w_styles, h_w_space, noise)
             # one discriminator pass over [fake; real] (samples are independent: same values as two passes,
             # :911-912, but twice the pixels per launch on the small maps)
+            if overlap_g:
+                # The generator forward of the G phase depends on nothing the D phase produces (same generator
+                # weights, own latents): it runs on a second stream beside the discriminator's forward / backward --
+                # two kernel mixes that stall on different resources (measured 20.4 -> 18.9 ms, tools/overlap_probe2.py).
+                # Ordered after the forward above (which also packed this step's generator weights).
+                main = torch.cuda.current_stream(dev)
+                side2 = self._g_stream()
+                side2.wait_event(main.record_event())
+                with torch.cuda.stream(side2):
+                    early = g_forward()
             if has_vq:   # the codebook's moving averages and its loss depend on the batch: two passes, reference order
                 fake_output, fake_q_loss = Disc(aug(generated_images, True))
                 real_output, real_q_loss = Disc(aug(image_batch))
@@ -406,12 +442,14 @@ class Trainer():
         set_requires_grad(Disc, False)
         d_updated = False
         for i in range(acc):
-            style = get_latents_fn(batch_size, num_layers - 2, latent_dim)
-            noise = self.rng.image_noise(batch_size, image_size)
-            batch = next(self.loader)
-            hist_batch = batch['histograms'].to(dev)
-            w_styles, h_w_space = self._w_and_hw(style, hist_batch)
-            generated_images = GAN.G(w_styles, h_w_space, noise)
+            if early is not None:
+                torch.cuda.current_stream(dev).wait_stream(self._g_stream())
+                for t in early:
+                    t.record_stream(torch.cuda.current_stream(dev))    # produced on the second stream, read on this one
+                noise, hist_batch, w_styles, h_w_space, generated_images = early
+                early = None
+            else:
+                noise, hist_batch, w_styles, h_w_space, generated_images = g_forward()
             if not d_updated:           # D must be updated before it scores the new fakes (reference order)
                 GAN._reduce_d.finish()
                 GAN.D_opt.step()
