@@ -29,6 +29,9 @@
 #ifndef HG_CONV_MINW
 #define HG_CONV_MINW 2   // __launch_bounds__ minimum waves per SIMD of k_conv (register budget 512 / MINW)
 #endif
+#ifndef HG_CONV_SETPRIO
+#define HG_CONV_SETPRIO 0
+#endif
 #ifndef HG_CONV_OPIPE
 #define HG_CONV_OPIPE 1  // explicit one-step-ahead operand pipeline in the MFMA loop of k_conv (+2.5 % on the generator layers)
 #endif
@@ -261,6 +264,11 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
       for (int j = 0; j < TP; ++j) bv[slot][j] = Xs[pixoff[j] + toff + kk * KS * g.CHS];
     };
     ldop(0, 0);
+#if HG_CONV_SETPRIO > 0
+    __builtin_amdgcn_s_setprio(HG_CONV_SETPRIO);   // waves in their MFMA phase go first: the staging of other waves fills in
+#elif HG_CONV_SETPRIO < 0
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
       if (s_ + 1 < NS) ldop(s_ + 1, (s_ + 1) & 1);
@@ -269,6 +277,11 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = M::mma(av[s_ & 1][i], bv[s_ & 1][j], acc[i][j]);
     }
+#if HG_CONV_SETPRIO > 0
+    __builtin_amdgcn_s_setprio(0);
+#elif HG_CONV_SETPRIO < 0
+    __builtin_amdgcn_s_setprio(-(HG_CONV_SETPRIO));   // staging / barrier phases go first, so waves return to their MFMAs sooner
+#endif
 #else
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {
