@@ -403,8 +403,6 @@ class Trainer():
             with torch.no_grad():   # the reference detaches this output; no graph is needed
                 w_styles, h_w_space = self._w_and_hw(style, hist_batch)
                 generated_images = GAN.G(w_styles, h_w_space, noise)
-            # one discriminator pass over [fake; real] (samples are independent: same values as two passes,
-            # :911-912, but twice the pixels per launch on the small maps)
             if overlap_g:
                 # The generator forward of the G phase depends on nothing the D phase produces (same generator
                 # weights, own latents): it runs on a second stream beside the discriminator's forward / backward --
@@ -419,6 +417,8 @@ class Trainer():
                 fake_output, fake_q_loss = Disc(aug(generated_images, True))
                 real_output, real_q_loss = Disc(aug(image_batch))
             else:
+                # one discriminator pass over [fake; real] (samples are independent: same values as two passes,
+                # :911-912, but twice the pixels per launch on the small maps)
                 both_output, both_q_loss = Disc(torch.cat((aug(generated_images, True), aug(image_batch)), dim=0))
                 fake_output, real_output = both_output[:batch_size], both_output[batch_size:]
                 fake_q_loss = real_q_loss = both_q_loss * 0.5
