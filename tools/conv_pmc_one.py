@@ -12,7 +12,7 @@ x = torch.randn(B, K, S, S, device=dev)
 w = torch.randn(N, K, 3, 3, device=dev) / (K * 9) ** 0.5
 go = torch.randn(B, N, S, S, device=dev)
 wf = C.pack_weights(w, C.PACK_FWD)
-for _ in range(4):
+for _ in range(int(os.environ.get('HG_ONE_ITERS', 4))):     # 4 for PMC passes; 60 for a steady-state kernel trace
     C.conv_fwd_packed(x, wf, N, 3)
     C.conv_wgrad(x, go, 3)
 cfg = HistConfig(h=64, insz=256, method='inverse-quadratic', sigma=0.02)
