@@ -66,7 +66,7 @@ class FlatParams:
         if getattr(self, '_gathered', True):
             return
         self.direct_ok = False
-        if self.direct_written:      # weight gradients written on the side stream: order them before any reader
+        if self.direct_written and self.grad.is_cuda:   # weight gradients written on the side stream: order them before any reader
             from .conv import side_stream
             torch.cuda.current_stream(self.grad.device).wait_stream(side_stream(self.grad.device))
         dst, src, missing, both = [], [], [], []

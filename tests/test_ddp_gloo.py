@@ -79,3 +79,32 @@ def test_single_process_is_identity():
     assert torch.all(flat.grad == 2.0)
     assert ddp.world_size() == 1 and ddp.rank() == 0
     assert ddp.all_reduce_scalar(3.5) == 3.5
+
+
+def test_flatparams_gather_with_directly_written_slots():
+    """FlatParams.gather(): slices written directly (conv._direct_wgrad, here simulated on CPU) are kept, autograd-delivered
+    gradients are copied in, a parameter that got both has them added, parameters without a gradient are zeroed."""
+    import torch
+    from histogan_amd.optim import FlatParams
+    ps = [torch.nn.Parameter(torch.randn(4, 3, 3, 3)), torch.nn.Parameter(torch.randn(5)),
+          torch.nn.Parameter(torch.randn(2, 3, 1, 1)), torch.nn.Parameter(torch.randn(7))]
+    flat = FlatParams(ps)
+    flat.grad.fill_(123.0)                       # stale content of the previous step
+    flat.zero_grad()
+    assert flat.direct_ok and all(p.grad is None for p in ps)
+    base = flat.grad.data_ptr()
+    offs = [0, ps[0].numel(), ps[0].numel() + ps[1].numel(), ps[0].numel() + ps[1].numel() + ps[2].numel()]
+    d0, d2 = torch.randn(ps[0].shape), torch.randn(ps[2].shape)
+    flat.grad[offs[0]:offs[0] + ps[0].numel()].copy_(d0.reshape(-1)); flat.direct_written.add(base + 4 * offs[0])
+    flat.grad[offs[2]:offs[2] + ps[2].numel()].copy_(d2.reshape(-1)); flat.direct_written.add(base + 4 * offs[2])
+    a1, a2 = torch.randn(5), torch.randn(ps[2].shape)
+    ps[1].grad = a1.clone()                      # delivered by autograd only
+    ps[2].grad = a2.clone()                      # delivered by autograd AND written directly
+    flat.gather()
+    assert not flat.direct_ok
+    assert torch.equal(ps[0].grad, d0) and torch.equal(ps[1].grad, a1) and torch.allclose(ps[2].grad, d2 + a2)
+    assert torch.equal(ps[3].grad, torch.zeros(7))
+    for p, o in zip(ps, offs):
+        assert p.grad.data_ptr() == base + 4 * o            # every .grad is the slice of the flat buffer again
+    flat.gather()                                # idempotent
+    assert torch.equal(ps[0].grad, d0)
