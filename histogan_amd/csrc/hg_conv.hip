@@ -36,16 +36,16 @@
 #define HG_CONV_OPIPE 1  // explicit one-step-ahead operand pipeline in the MFMA loop of k_conv (+2.5 % on the generator layers)
 #endif
 #ifndef HG_CONV_KC
-#define HG_CONV_KC 4
+#define HG_CONV_KC 4     // input channels per K chunk of the stride-1 tiles (64x64 tile: twice that); 2/4/8 measure within 3 %
+#endif
 #ifndef HG_WGRAD_TS_DBUF
 #define HG_WGRAD_TS_DBUF 0   // double-buffering the tap-split pixel-split tiles: measured no gain
 #endif
 #ifndef HG_WGRAD_TAPSPLIT
-#define HG_WGRAD_TAPSPLIT 2   // k_wgrad 2x2-tile blocks: the three kernel rows on three waves (12 waves, 3 per SIMD)
+#define HG_WGRAD_TAPSPLIT 2   // k_wgrad: the three kernel rows of a tile on three waves (1: 2x2-tile blocks only, 2: all 3x3 tiles)
 #endif
 #ifndef HG_CONV_BIGTILE_SPLITK
-#define HG_CONV_BIGTILE_SPLITK 2
-#endif     // input channels per K chunk of the stride-1 tiles (64x64 tile: twice that); 2/4/8 measure within 3 %
+#define HG_CONV_BIGTILE_SPLITK 2   // 128x128 tile + K split for 8x8 maps (1) and 4x4 maps (2)
 #endif
 
 namespace {
