@@ -24,8 +24,7 @@ _skip_wgrad = False
 #   'f32'   v_mfma_f32_32x32x2_f32 (k_conv)            -- default
 #   'b6'    three-way bf16 split, six bf16 MFMAs per fp32 product sum (k_conv_b6): fp32-level accuracy at 2.7x the
 #           fp32-MFMA ceiling.  Used for layers with >= 16 input channels and >= B6_MIN_PIX output pixels.
-import os as _os
-PRECISION = _os.environ.get('HG_CONV_PRECISION', 'f32')
+PRECISION = os.environ.get('HG_CONV_PRECISION', 'f32')
 B6_MIN_PIX = 4096
 
 
