@@ -332,7 +332,9 @@ class recoloringTrainer():
                 side2.wait_event(main.record_event())     # after the forward above (it packed this step's weights)
                 with torch.cuda.stream(side2):
                     early = g_forward()
-            if any(q is not None for q in Disc.quantize_blocks):      # batch-dependent codebook: two passes
+            # two passes with feature quantisation (batch-dependent codebook) and on gradient-penalty steps (the double
+            # backward then covers the real half only)
+            if apply_gradient_penalty or any(q is not None for q in Disc.quantize_blocks):
                 fake_output, fake_q_loss = Disc(generated_images)
                 real_output, real_q_loss = Disc(image_batch)
                 quantize_loss = (fake_q_loss + real_q_loss).mean()

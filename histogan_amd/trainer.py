@@ -413,7 +413,10 @@ class Trainer():
                 side2.wait_event(main.record_event())
                 with torch.cuda.stream(side2):
                     early = g_forward()
-            if has_vq:   # the codebook's moving averages and its loss depend on the batch: two passes, reference order
+            # two passes, reference order: with feature quantisation (the codebook's moving averages and its loss depend
+            # on the batch) and on gradient-penalty steps (the penalty's double backward then covers the real half only,
+            # not a [fake; real] batch whose fake half carries zero gradients)
+            if has_vq or apply_gradient_penalty:
                 fake_output, fake_q_loss = Disc(aug(generated_images, True))
                 real_output, real_q_loss = Disc(aug(image_batch))
             else:
