@@ -1,0 +1,107 @@
+"""GPU parity at the shapes the bench numbers are quoted on: the HIP histogram through the C ABI
+vs outputs of the UNMODIFIED reference (tests/golden/big_*.npz, made by tests/golden/make_golden_big.py) on
+configs[0] (4x3x128^2), configs[1]'s per-image shape (256^2, insz=256, N = 65 536: 1 024-pixel wave chunks x 16
+split-K slabs), the trainer default (256^2 -> 150^2 bilinear), h = 128, a 1024^2 photograph, and the RBF /
+thresholding kernels at N = 65 536.  Bars: forward 1e-5, gradient 1e-4 (max-norm relative), loss 1e-4
+absolute; and our distance to an fp64 evaluation of the same formulas must stay within 2x the reference's own."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from bigcases import big_names, load_big, rand_grad_out
+from conftest import relmax
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL, BWD_TOL, LOSS_TOL = 1e-5, 1e-4, 1e-4
+
+
+def _block(kw):
+    from histogram_classes.RGBuvHistBlock import RGBuvHistBlock
+    return RGBuvHistBlock(device='cuda', **kw)
+
+
+def _run(g, dev, upstream):
+    """-> (hist, loss or None, grad_x) of the HIP path; upstream = 'hell' | 'rand'."""
+    from histogan_amd.hist import hellinger_loss
+    spec = g['spec']
+    x = g['x'].to(dev).requires_grad_(True)
+    out = _block(spec['kw'])(F.relu(x) if spec.get('relu') else x)
+    if upstream == 'hell':
+        loss = hellinger_loss(torch.from_numpy(g['target_hist']).to(dev), out)
+        loss.backward()
+        return out.detach(), float(loss), x.grad
+    out.backward(rand_grad_out(out.shape).to(dev))
+    return out.detach(), None, x.grad
+
+
+@pytest.mark.parametrize('name', big_names())
+def test_forward_and_gradient_match_reference_at_baseline_shapes(name, gpu_device):
+    g = load_big(name)
+    if 'hell_loss' in g:
+        out, loss, gx = _run(g, gpu_device, 'hell')
+        assert out.shape == g['hist'].shape
+        assert relmax(out.cpu().numpy(), g['hist']) <= FWD_TOL
+        assert abs(loss - float(g['hell_loss'])) <= LOSS_TOL
+        gx = gx.cpu().numpy()
+        if 'hell_grad_x' in g:
+            assert relmax(gx, g['hell_grad_x']) <= BWD_TOL
+        else:                                    # 1024^2: stride-s lattice + per-channel sums of the full gradient
+            s = g['spec']['grad_stride']
+            amax = float(g['hell_grad_x_absmax'])
+            assert np.max(np.abs(gx[:, :, ::s, ::s] - g['hell_grad_x_lattice'])) / amax <= BWD_TOL
+            assert abs(float(np.abs(gx).max()) - amax) / amax <= BWD_TOL
+            cs = gx.astype(np.float64).sum(axis=(2, 3))
+            scale = np.abs(gx).astype(np.float64).sum(axis=(2, 3))
+            assert np.max(np.abs(cs - g['hell_grad_x_chansum']) / scale) <= BWD_TOL
+    if 'grad_x' in g:
+        out, _, gx = _run(g, gpu_device, 'rand')
+        assert relmax(out.cpu().numpy(), g['hist']) <= FWD_TOL
+        assert relmax(gx.cpu().numpy(), g['grad_x']) <= BWD_TOL
+
+
+@pytest.mark.parametrize('name', ['c1_4x128', 'c2_2x256_uniform', 'trainer_2x256to150'])
+def test_distance_to_fp64_truth_within_twice_the_references(name, gpu_device):
+    """ours-vs-fp64 error <= 2x reference-vs-fp64 error (forward and Hellinger gradient).  The fp64
+    evaluation is the oracle's truth mode (every stage in double) run here on the host."""
+    from oracle import rgbuv_hist as O
+    g = load_big(name)
+    spec = g['spec']
+    xt = g['x'].clone().requires_grad_(True)
+    tout = O.rgbuv_hist(F.relu(xt) if spec.get('relu') else xt, truth=True, **spec['kw'])
+    tloss = O.hellinger_loss(torch.from_numpy(g['target_hist']).double(), tout)
+    (tgx,) = torch.autograd.grad(tloss, xt)
+    tout, tgx = tout.detach().numpy(), tgx.numpy()
+    out, loss, gx = _run(g, gpu_device, 'hell')
+    e_ref_f, e_our_f = relmax(g['hist'], tout), relmax(out.cpu().numpy(), tout)
+    e_ref_b, e_our_b = relmax(g['hell_grad_x'], tgx), relmax(gx.cpu().numpy(), tgx)
+    print(f'{name}: fwd ours {e_our_f:.2e} ref {e_ref_f:.2e} | grad ours {e_our_b:.2e} ref {e_ref_b:.2e}')
+    assert e_our_f <= 2 * e_ref_f
+    assert e_our_b <= 2 * e_ref_b
+    assert abs(loss - float(tloss)) <= 2 * abs(float(g['hell_loss']) - float(tloss)) + 1e-7
+
+
+def test_full_bench_batch_properties(gpu_device):
+    """configs[1] at its full size (32x3x256^2, h=64, insz=256): size-independent properties -- every image's
+    histogram equals the one computed alone / in the 2-image golden batch (batch independence, bitwise), sums to 1,
+    the gradient of image i does not depend on its batch mates, and repeat runs are bit-identical."""
+    g = load_big('c2_2x256_uniform')
+    blk = _block(g['spec']['kw'])
+    gen = torch.Generator().manual_seed(123)
+    x = torch.rand(32, 3, 256, 256, generator=gen)
+    x[:2] = g['x']
+    xg = x.to(gpu_device).requires_grad_(True)
+    out = blk(xg)
+    assert relmax(out[:2].detach().cpu().numpy(), g['hist']) <= FWD_TOL
+    s = out.detach().sum(dim=(1, 2, 3)).cpu().numpy()
+    assert np.max(np.abs(s - 1.0)) <= 1e-5
+    go = rand_grad_out(out.shape).to(gpu_device)
+    out.backward(go)
+    x1 = x[5:6].to(gpu_device).requires_grad_(True)
+    o1 = blk(x1)
+    o1.backward(go[5:6])
+    assert relmax(o1.detach().cpu().numpy(), out[5:6].detach().cpu().numpy()) <= 1e-6
+    assert relmax(x1.grad.cpu().numpy(), xg.grad[5:6].cpu().numpy()) <= 1e-5
+    again = blk(x.to(gpu_device))
+    assert torch.equal(again, out.detach())
