@@ -610,6 +610,165 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Plane-at-a-time MFMA backward: any hist_boundary, h <= 32*RT <= 128, the one-plane projections (rg-chroma, Lab)
+// and green_only.  The mirrored-table merge of k_hist_bwd needs lo == -hi and all of Ghat (3 x h x (h+1) floats) in
+// LDS; here ONE plane's Ghat is resident (h = 128: 66 KB, two workgroups per CU) and the workgroup walks its pixels
+// once per plane, the reference's plane structure taken literally (RGBuvHistBlock.py:112-148, 150-187, 190-222):
+//   Wu[i] = sum_j Ghat_p[i][j] k(v-b_j)      Wv[j] = sum_i Ghat_p[i][j] k(u-b_i)          (u, v) of plane p
+//   dL/du = Iy sum_i k'(u-b_i) Wu[i]          dL/dv = Iy sum_j k'(v-b_j) Wv[j]             dL/dIy += sum_i k(u-b_i) Wu[i]
+// as D[bin][pixel] tiles exactly like k_hist_bwd (same K-index permutation beta0, same double-single t, kernel
+// values re-evaluated in the epilogue): 2*RT MFMAs per K step against 2 kernel evaluations.  (da, db, dc, dIy) of a
+// pixel are carried from plane to plane through `part` ([B][4][npix] floats, written and re-read by the same lane);
+// the last plane applies the chain rule and stores.  Replaces the one-pixel-per-lane fp64 k_hist_bwd_generic for every
+// smooth-kernel case up to h = 128 (configs[4]: h = 128).
+template <int RT>
+struct POps { float Au[RT], Av[RT]; float ku, kv; };
+
+template <int RT, int METHOD>
+__global__ __launch_bounds__(256, 2) void k_hist_bwd_planes(const DevParams P, const float *__restrict__ x,
+                                                            const float *__restrict__ gout,
+                                                            const float *__restrict__ hist,
+                                                            const float *__restrict__ sums, float *__restrict__ part,
+                                                            float *__restrict__ gdst, const int rounds_per_wave) {
+  constexpr int BLK = 32 * RT, NS = 16 * RT, LD = BLK + 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *G = reinterpret_cast<float *>(smem);  // [BLK][LD]: Ghat of the current plane, zero-padded
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int half = lane >> 5, q = lane & 31;
+  const int b = blockIdx.y, s_ = blockIdx.x;
+  const float *xb = x + (long long)b * P.sb;
+  const int h = P.h, nplanes = P.P;
+  const float *g = gout + (long long)b * nplanes * h * h, *o = hist + (long long)b * nplanes * h * h;
+  float dot = 0.f;
+  for (int e = threadIdx.x; e < nplanes * h * h; e += 256) dot = fmaf(g[e], o[e], dot);
+  dot = hg_block_sum_256(dot, G);  // <G, out>
+  const float inv = 1.f / sums[b];
+  float *pb = part + (long long)b * 4 * P.npix;
+  const long long wstart = ((long long)(s_ * 4 + wave) * rounds_per_wave) * 32;
+
+  for (int pi = 0; pi < nplanes; ++pi) {
+    const int p = P.green ? 1 : pi;                   // geometric plane: (u, v) = (a, b) | (-a, c) | (-b, -c)
+    __syncthreads();                                  // the previous plane's operand reads are done
+    for (int e = threadIdx.x; e < BLK * BLK; e += 256) {
+      const int I = e / BLK, J = e - I * BLK;
+      G[I * LD + J] = (I < h && J < h) ? (g[((long long)pi * h + I) * h + J] - dot) * inv : 0.f;
+    }
+    __syncthreads();
+
+    for (int rd = 0; rd < rounds_per_wave; ++rd) {
+      const long long n0 = wstart + (long long)rd * 32;
+      if (n0 >= P.npix) break;
+      const int n = (int)n0 + q;
+      const bool valid = n < P.npix;
+      float r_ = 0.f, g_ = 0.f, b_ = 0.f;
+      if (valid) sample_rgb(P, xb, n, r_, g_, b_);
+      float a, bb, c, iy;
+      project(P, r_, g_, b_, a, bb, c, iy);
+      const float u = (p == 0) ? a : (p == 1 ? -a : -bb), v = (p == 0) ? bb : (p == 1 ? c : -c);
+
+      // t_s = (u - lo - 4*half*step)/sigma - beta0(s)*step/sigma, double-single (beta0(s) < 128: beta0*ds_hi exact)
+      float th[2], tl[2];
+      {
+        const double tu = ((double)u - P.lo - (double)(4 * half) * P.step) * P.inv_sigma_x;
+        const double tv = ((double)v - P.lo - (double)(4 * half) * P.step) * P.inv_sigma_x;
+        th[0] = (float)tu; tl[0] = (float)(tu - (double)th[0]);
+        th[1] = (float)tv; tl[1] = (float)(tv - (double)th[1]);
+      }
+      auto kern = [&](float t) -> float {
+        if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) return __builtin_amdgcn_rcpf(fmaf(t, t, 1.f));
+        else return expf(-(t * t));
+      };
+
+      f32x16 Wu[RT], Wv[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Wu[t][r] = 0.f; Wv[t][r] = 0.f; }
+
+      auto make_ops = [&](int s, POps<RT> &op) {
+        const int b0 = beta0(s);
+        const int beta = b0 + 4 * half;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = 32 * rt + q;
+          op.Au[rt] = G[row * LD + beta];
+          op.Av[rt] = G[beta * LD + row];
+        }
+        const float kf = -(float)b0;
+        op.ku = kern(fmaf(kf, P.ds_hi, th[0]) + fmaf(kf, P.ds_lo, tl[0]));
+        op.kv = kern(fmaf(kf, P.ds_hi, th[1]) + fmaf(kf, P.ds_lo, tl[1]));
+      };
+      POps<RT> cur;
+      make_ops(0, cur);
+#pragma unroll 1
+      for (int s = 0; s < NS; ++s) {
+        POps<RT> nxt;
+        make_ops(min(s + 1, NS - 1), nxt);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          Wu[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.Au[rt], cur.kv, Wu[rt], 0, 0, 0);
+          Wv[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.Av[rt], cur.ku, Wv[rt], 0, 0, 0);
+        }
+#if HG_BWD_SCHED_GROUPS
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * RT, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * RT; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+#endif
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) asm volatile("" : "+v"(nxt.Au[rt]), "+v"(nxt.Av[rt]));
+        cur = nxt;
+      }
+
+      // epilogue: this lane holds W*[t][r] for bin beta0(16t+r)+4*half of pixel q; kernel values re-evaluated
+      asm volatile("" : "+v"(th[0]), "+v"(tl[0]), "+v"(th[1]), "+v"(tl[1]));
+      float gu = 0.f, gv = 0.f, isum = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const float kf = -(float)beta0(s);
+        const float tu = fmaf(kf, P.ds_hi, th[0]) + fmaf(kf, P.ds_lo, tl[0]);
+        const float tv = fmaf(kf, P.ds_hi, th[1]) + fmaf(kf, P.ds_lo, tl[1]);
+        const float ku = kern(tu), kv = kern(tv);
+        const float kwu = ku * Wu[s >> 4][s & 15], kwv = kv * Wv[s >> 4][s & 15];
+        isum += kwu;
+        if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) { gu = fmaf(tu * ku, kwu, gu); gv = fmaf(tv * kv, kwv, gv); }
+        else { gu = fmaf(tu, kwu, gu); gv = fmaf(tv, kwv, gv); }
+#if HG_BWD_SCHED_BARRIER
+        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
+      gu += __shfl_xor(gu, 32, 64);
+      gv += __shfl_xor(gv, 32, 64);
+      isum += __shfl_xor(isum, 32, 64);
+      const float du = iy * P.dk_scale * gu, dv = iy * P.dk_scale * gv;   // dL/du, dL/dv of this plane
+
+      if (valid && half == 0) {
+        float da = 0.f, db = 0.f, dc = 0.f, dIy = 0.f;
+        if (pi > 0) { da = pb[n]; db = pb[P.npix + n]; dc = pb[2LL * P.npix + n]; dIy = pb[3LL * P.npix + n]; }
+        if (p == 0) { da += du; db += dv; }
+        else if (p == 1) { da -= du; dc += dv; }
+        else { db -= du; dc -= dv; }
+        dIy += isum;
+        if (pi + 1 < nplanes) {
+          pb[n] = da; pb[P.npix + n] = db; pb[2LL * P.npix + n] = dc; pb[3LL * P.npix + n] = dIy;
+        } else if (P.proj != HG_PROJ_RGBUV) {
+          // one plane binned as (u, v) = (-a, c): dL/du = -da, dL/dv = dc
+          store_pixel_grad_proj(P, xb, b, n, r_, g_, b_, iy, -da, dc, P.intensity ? dIy : 0.f, gdst);
+        } else {
+          store_pixel_grad(P, xb, b, n, r_, g_, b_, iy, da, db, dc, P.intensity ? dIy : 0.f, gdst);
+        }
+      }
+      if (valid && half == 1 && pi + 1 == nplanes && P.mode == HG_RESIZE_NONE) {
+        for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Generic backward (any h, any hist_boundary): the reference's plane structure taken literally,
 // one pixel per lane, fp64 kernel evaluation, fp32 mat-vecs against Ghat held in global/L2 (every
 // lane reads the same Ghat element -> one broadcast load).  Used where the MFMA kernel does not
@@ -1056,6 +1215,7 @@ struct Plan {
   int nparts;                // reduce blocks per image
   int S_bwd, rounds;         // backward: WGs per image, 32-pixel rounds per wave
   size_t slab_bytes, part_bytes, gh_bytes, gxs_bytes;
+  int planes_rt;             // > 0: backward on k_hist_bwd_planes<planes_rt> (see bwd_planes_rt)
 };
 
 int validate(const hg_hist_params *p) {
@@ -1089,6 +1249,17 @@ inline int rbf_radius(const hg_hist_params *p) {
 }
 
 inline bool sparse_path(const hg_hist_params *p) { return thr_scatter(p) || rbf_radius(p) > 0; }
+
+// Which backward kernel?  0: k_hist_bwd (symmetric boundary, h <= 64, RGB-uv) or, for thresholding beyond the scatter
+// path / h > 128, k_hist_bwd_generic.  RT > 0: k_hist_bwd_planes<RT> -- smooth kernels with an asymmetric boundary,
+// 64 < h <= 128, or a one-plane projection.  HG_BWD_PLANES=1 sends the symmetric h <= 64 case there too (A/B runs,
+// and the parity test of one MFMA formulation against the other).
+inline int bwd_planes_rt(const hg_hist_params *p, int nbd) {
+  if (p->method == HG_METHOD_THRESHOLDING || sparse_path(p) || p->h > 128) return 0;
+  bool want = (p->lo != -p->hi) || nbd != 1 || p->projection != HG_PROJ_RGBUV;
+  if (const char *e = getenv("HG_BWD_PLANES")) { if (atoi(e) == 1) want = true; else if (atoi(e) == 0) want = false; }
+  return want ? (p->h + 31) / 32 : 0;
+}
 
 Plan make_plan(const hg_hist_params *p) {
   Plan pl;
@@ -1130,7 +1301,11 @@ Plan make_plan(const hg_hist_params *p) {
   pl.S_bwd = (int)Sb;
   pl.rounds = (int)rpw;
   // generic backward only (h > 64 or asymmetric boundary): Ghat in natural layout
-  pl.gh_bytes = ((p->lo != -p->hi) || pl.nbd != 1 || p->projection || sparse_path(p)) ? ((size_t)p->B * n_per_img * sizeof(float) + 255) / 256 * 256 : 256;
+  pl.planes_rt = bwd_planes_rt(p, pl.nbd);
+  if (pl.planes_rt)   // (da, db, dc, dIy) per pixel, carried from plane to plane
+    pl.gh_bytes = (P == 3) ? ((size_t)p->B * 4 * npix * sizeof(float) + 255) / 256 * 256 : 256;
+  else
+    pl.gh_bytes = ((p->lo != -p->hi) || pl.nbd != 1 || p->projection || sparse_path(p)) ? ((size_t)p->B * n_per_img * sizeof(float) + 255) / 256 * 256 : 256;
   pl.gxs_bytes = (p->resize_mode == HG_RESIZE_NONE) ? 0 : ((size_t)p->B * 3 * npix * sizeof(float) + 255) / 256 * 256;
   return pl;
 }
@@ -1205,6 +1380,35 @@ int launch_bwd_t(const DevParams &d, const Plan &pl, const float *x, const float
     case HG_METHOD_THRESHOLDING: return launch_bwd_tm<T, HG_METHOD_THRESHOLDING>(d, pl, x, gout, hist, sums, gdst, st);
     case HG_METHOD_RBF: return launch_bwd_tm<T, HG_METHOD_RBF>(d, pl, x, gout, hist, sums, gdst, st);
     default: return launch_bwd_tm<T, HG_METHOD_INVERSE_QUADRATIC>(d, pl, x, gout, hist, sums, gdst, st);
+  }
+}
+
+template <int RT>
+int launch_bwd_planes_rt(const DevParams &d, const Plan &pl, const float *x, const float *gout, const float *hist,
+                         const float *sums, float *part, float *gdst, hipStream_t st) {
+  const dim3 grid(pl.S_bwd, d.B), block(256);
+  const size_t lds = (size_t)(32 * RT) * (32 * RT + 1) * sizeof(float);
+  const void *kern = (d.method == HG_METHOD_RBF) ? (const void *)k_hist_bwd_planes<RT, HG_METHOD_RBF>
+                                                 : (const void *)k_hist_bwd_planes<RT, HG_METHOD_INVERSE_QUADRATIC>;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (d.method == HG_METHOD_RBF)
+    hipLaunchKernelGGL((k_hist_bwd_planes<RT, HG_METHOD_RBF>), grid, block, lds, st, d, x, gout, hist, sums, part, gdst, pl.rounds);
+  else
+    hipLaunchKernelGGL((k_hist_bwd_planes<RT, HG_METHOD_INVERSE_QUADRATIC>), grid, block, lds, st, d, x, gout, hist, sums, part, gdst, pl.rounds);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+int launch_bwd_planes(const DevParams &d, const Plan &pl, const float *x, const float *gout, const float *hist,
+                      const float *sums, float *part, float *gdst, hipStream_t st) {
+  switch (pl.planes_rt) {
+    case 1: return launch_bwd_planes_rt<1>(d, pl, x, gout, hist, sums, part, gdst, st);
+    case 2: return launch_bwd_planes_rt<2>(d, pl, x, gout, hist, sums, part, gdst, st);
+    case 3: return launch_bwd_planes_rt<3>(d, pl, x, gout, hist, sums, part, gdst, st);
+    default: return launch_bwd_planes_rt<4>(d, pl, x, gout, hist, sums, part, gdst, st);
   }
 }
 
@@ -1308,6 +1512,10 @@ int hg_rgbuv_hist_bwd(const hg_hist_params *p, const float *x, const float *grad
     if (R) hipLaunchKernelGGL(k_hist_rbf_bwd, dim3((d.npix + 255) / 256, d.B), dim3(256), 0, st, d, x, gh, gdst, R);
     else hipLaunchKernelGGL(k_hist_thr_bwd, dim3((d.npix + 255) / 256, d.B), dim3(256), 0, st, d, x, gh, gdst);
     HG_LAUNCH_CHECK();
+  } else if (pl.planes_rt) {
+    float *part = (float *)((char *)workspace + pl.gxs_bytes);
+    int r = launch_bwd_planes(d, pl, x, grad_out, hist_out, sum_out, part, gdst, st);
+    if (r) return r;
   } else if (!generic) {
     int r = (pl.T == 1) ? launch_bwd_t<1>(d, pl, x, grad_out, hist_out, sum_out, gdst, st)
                         : launch_bwd_t<2>(d, pl, x, grad_out, hist_out, sum_out, gdst, st);

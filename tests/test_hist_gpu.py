@@ -172,3 +172,59 @@ def test_rbf_truncated_scatter_matches_oracle(kw, gpu_device, monkeypatch):
     dense.backward(go.to(gpu_device))
     assert relmax(out.detach().cpu().numpy(), dense.detach().cpu().numpy()) <= 2e-6
     assert relmax(xg.grad.cpu().numpy(), xd.grad.cpu().numpy()) <= 2e-5
+
+
+PLANES_CASES = [
+    dict(h=128, insz=150),                                                       # configs[4]: RT = 4, 66 KB of LDS
+    dict(h=128, insz=64, hist_boundary=[-2.5, 3.5], sigma=0.05),                 # h = 128 and asymmetric
+    dict(h=96, insz=40, resizing='interpolation'),                               # RT = 3, zero-padded rows, resize adjoint
+    dict(h=64, insz=64, hist_boundary=[-2.0, 4.0]),                              # asymmetric at the default size
+    dict(h=40, insz=64, hist_boundary=[-3.0, 1.0], intensity_scale=False),
+    dict(h=16, insz=20, hist_boundary=[0.5, 3.0], resizing='sampling', green_only=True),
+    dict(h=72, insz=64, method='RBF', sigma=0.5),                                # wide RBF: dense path
+    dict(h=32, insz=64, method='RBF', sigma=0.4, hist_boundary=[-1.0, 3.0]),
+]
+
+
+@pytest.mark.parametrize('kw', PLANES_CASES)
+def test_plane_backward_matches_oracle(kw, gpu_device):
+    """k_hist_bwd_planes (asymmetric boundary / 64 < h <= 128 / one plane): gradient vs the oracle's autograd."""
+    from oracle import rgbuv_hist as O
+    g = torch.Generator().manual_seed(kw['h'] + 7)
+    x = (torch.rand(2, 4, 48, 56, generator=g) * 1.2 - 0.1)
+    x[0, :, :4] = 0.0; x[1, :, 5:9, 5:9] = 1.0
+    blk = _block(kw)
+    xg = x.to(gpu_device).requires_grad_(True)
+    out = blk(xg)
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.to(gpu_device))
+    xo = x.clone().requires_grad_(True)
+    ref = O.rgbuv_hist(xo, **kw)
+    ref.backward(go)
+    assert relmax(out.detach().cpu().numpy(), ref.detach().numpy()) <= FWD_TOL
+    assert relmax(xg.grad.cpu().numpy(), xo.grad.numpy()) <= BWD_TOL
+    assert float(xg.grad[:, 3].abs().max()) == 0.0                              # channels >= 3 get zeros
+    xg.grad = None
+    blk(xg).backward(go.to(gpu_device))
+    # bit-identical repeat (no atomics) -- except through the sampling adjoint's atomicAdd when a side < h
+    if kw.get('resizing') != 'sampling':
+        x2 = x.to(gpu_device).requires_grad_(True)
+        blk(x2).backward(go.to(gpu_device))
+        assert torch.equal(x2.grad, xg.grad)
+
+
+@pytest.mark.parametrize('h,method,sigma', [(64, 'inverse-quadratic', 0.02), (32, 'inverse-quadratic', 0.05),
+                                            (64, 'RBF', 0.3)])
+def test_plane_backward_matches_merged_backward(h, method, sigma, gpu_device, monkeypatch):
+    """Two MFMA formulations of the same gradient: the mirrored-table kernel (k_hist_bwd, default for a symmetric
+    boundary and h <= 64) and the plane-at-a-time kernel (HG_BWD_PLANES=1)."""
+    g = torch.Generator().manual_seed(h)
+    x = torch.rand(3, 3, 64, 80, generator=g)
+    blk = _block(dict(h=h, insz=128, method=method, sigma=sigma))
+    go = (torch.rand(3, 3, h, h, generator=g) - 0.3).to(gpu_device)
+    xa = x.to(gpu_device).requires_grad_(True)
+    blk(xa).backward(go)
+    monkeypatch.setenv('HG_BWD_PLANES', '1')
+    xb = x.to(gpu_device).requires_grad_(True)
+    blk(xb).backward(go)
+    assert relmax(xb.grad.cpu().numpy(), xa.grad.cpu().numpy()) <= 1e-5
