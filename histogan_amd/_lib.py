@@ -58,6 +58,8 @@ def _load():
     lib.hg_hellinger_workspace_bytes.argtypes = [i64]
     lib.hg_hellinger_fwd_bwd.restype = ctypes.c_int
     lib.hg_hellinger_fwd_bwd.argtypes = [vp, vp, i64, i32, f32, vp, vp, vp, sz, vp]
+    lib.hg_selftest_fastlog.restype = ctypes.c_int
+    lib.hg_selftest_fastlog.argtypes = [vp, vp]
     # include/hg_nets.h
     lib.hg_modulate_fwd.restype = ctypes.c_int
     lib.hg_modulate_fwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
@@ -127,7 +129,7 @@ lib = _load()
 
 # every symbol include/hg_hist.h, hg_nets.h, hg_conv.h, hg_recolor.h and hg_augment.h declare
 EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_fwd',
-           'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd',
+           'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd', 'hg_selftest_fastlog',
            'hg_modulate_fwd', 'hg_modulate_bwd', 'hg_demod_noise_lrelu_fwd', 'hg_demod_noise_lrelu_bwd',
            'hg_diffgrad_step', 'hg_ema_update', 'hg_nets_workspace_bytes', 'hg_channel_sum',
            'hg_conv_packed_elems', 'hg_conv_pack_weights', 'hg_conv_pack_weights_both', 'hg_conv2d_fwd', 'hg_modconv2d_fwd', 'hg_conv2d_workspace_bytes', 'hg_conv2d_dgrad',

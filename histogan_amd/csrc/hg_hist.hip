@@ -910,14 +910,184 @@ __device__ __forceinline__ void thr_scatter_plane(const DevParams &P, unsigned l
   }
 }
 
+// exact (integer) total of a workgroup's fixed-point grid; NT threads, result in every thread
+template <int NT>
+__device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v, unsigned long long *sm /* NT/64 */) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long t = 0ull;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) t += sm[w];
+  __syncthreads();
+  return t;
+}
+
+// Scatter paths: slab sum + normalisation in ONE launch (k_hist_reduce + k_hist_normalize of the dense path).  The
+// scatter kernels leave the exact total of every slab (integer sum of its fixed-point grid) in slab_tot[b][s], so the
+// normaliser of RGBuvHistBlock.py:224-228 needs no second pass over the histogram.
+__global__ __launch_bounds__(256) void k_hist_finish(const float *__restrict__ slabs, const double *__restrict__ slab_tot,
+                                                     float *__restrict__ hist, float *__restrict__ sum_out, int S,
+                                                     int n_per_img) {
+  __shared__ double st[256];
+  const int b = blockIdx.y;
+  // the slab totals are fetched by S threads at once (a serial loop would pay S memory latencies) and summed in slab
+  // order by everyone
+  const int Sl = S < 256 ? S : 256;
+  if ((int)threadIdx.x < Sl) st[threadIdx.x] = slab_tot[b * S + threadIdx.x];
+  __syncthreads();
+  double tot = 0.0;
+  for (int s = 0; s < Sl; ++s) tot += st[s];
+  for (int s = 256; s < S; ++s) tot += slab_tot[b * S + s];       // more slabs than threads: never at these sizes
+  const float den = (float)tot + kEps;
+  if (blockIdx.x == 0 && threadIdx.x == 0) sum_out[b] = den;
+  const float *src = slabs + (long long)b * S * n_per_img;
+  const int e0 = blockIdx.x * 1024 + threadIdx.x;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < S; s += 4) {                                 // 16 independent loads in flight, summed in slab order
+    float t[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = e0 + k * 256;
+        t[u][k] = (s + u < S && e < n_per_img) ? src[(long long)(s + u) * n_per_img + e] : 0.f;
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] += t[u][k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int e = e0 + k * 256;
+    if (e < n_per_img) hist[(long long)b * n_per_img + e] = v[k] / den;
+  }
+}
+
+// ---- fast window classification ------------------------------------------------------------------------------
+// The scatter kernels were bound by the three fp64 logarithms per pixel (~35 us of fp64 VALU work at configs[1]
+// against 4 us of HBM time).  Those logs exist to make u bit-identical to the reference so that the 0/1 window
+// decision |u - b_i| <= eps/2 is the reference's; but the decision only depends on the last bits of u when u sits
+// within rounding distance of a window edge.  So: classify with v_log_f32 (|error| <= kFastLogRel * |ln x|, checked
+// exhaustively by hg_selftest_fastlog) and fp32 bin arithmetic carrying an explicit error bound `m`; a value
+// farther than m from both window edges has the same decision as the exact evaluation.  Pixels with any of their six
+// values inside a margin (about 1 in 3 000) take the exact fp64 path.  Identical histograms, bit for bit
+// (tests: fast vs HG_THR_EXACT=1).
+constexpr float kFastLogRel = 3.6e-7f;   // margin per unit of |ln x1| + |ln x2|: log error (measured max <= 2.4e-7) + rounding of the difference (6e-8)
+
+// ln x for normal x > 0 on the transcendental unit: v_log_f32 (log2, ~1 ulp) times ln 2 -- two instructions.  (__logf
+// would add denormal scaling and an extended-precision multiply: 12 instructions for the same 2-ulp result here.)
+__device__ __forceinline__ float fast_ln(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
+// Classification runs in bin units: t = (v - lo)/step as ONE fma, nearest bin rint(t), distance |t - rint(t)| (exact)
+// against the window half-width eps/(2 step).  mt0 bounds the roundings of that fma (constants and result, all
+// proportional to the size of t <= h) in bin units.
+struct ThrFast {
+  float inv_step, c0;      // t = fma(v, inv_step, c0), c0 = -lo/step
+  float thr_t;             // eps / (2 step)
+  float mt0, mrel;         // margin (bin units) = mt0 + mrel * (|ln x1| + |ln x2|)
+  unsigned hmax;           // h - 1
+};
+
+__device__ __forceinline__ ThrFast make_thr_fast(const DevParams &P) {
+  ThrFast F;
+  const double is = P.step > 0.0 ? 1.0 / P.step : 0.0;
+  F.inv_step = (float)is;
+  F.c0 = (float)(-P.lo * is);
+  F.thr_t = (float)(P.half_eps * is);
+  F.mt0 = 2.5e-7f * (float)P.h + 1.0e-7f * F.inv_step;
+  F.mrel = kFastLogRel * F.inv_step;
+  F.hmax = (unsigned)(P.h - 1);
+  return F;
+}
+
+// one value: bin index or -1; unsafe |= decision within the margin
+__device__ __forceinline__ int thr_fast_one(const ThrFast &F, float v, float m, bool &unsafe) {
+  const float t = fmaf(v, F.inv_step, F.c0);
+  const float fi = rintf(t);
+  const float dt = fabsf(t - fi);
+  unsafe |= fabsf(dt - F.thr_t) <= m;
+  const int i = (int)fi;                                   // saturating conversion; out-of-range fails the unsigned test
+  return (dt < F.thr_t && (unsigned)i <= F.hmax) ? i : -1;
+}
+
+// Iy -> 2^32 fixed point, round half up: exactly (unsigned long long)((double)iy * 2^32 + 0.5), from the float's bits
+__device__ __forceinline__ unsigned long long iy_fixed(float iy) {
+  const unsigned bits = __float_as_uint(iy);
+  const int sh = (int)(bits >> 23) - 118;                  // iy = m * 2^(e-150), times 2^32
+  const unsigned m = (bits & 0x7FFFFFu) | 0x800000u;
+  if (sh >= 0) return (unsigned long long)m << sh;         // iy >= 2^-9 (and < 2^33): an integer already
+  const int s = -sh;
+  if (s >= 25) return 0ull;                                // iy < 2^-34: rounds to 0
+  return (unsigned long long)((m >> s) + ((m >> (s - 1)) & 1u));
+}
+
+// RGB-uv, `single` windows: the six bin indices (plane p: idx[2p] = u bin, idx[2p+1] = v bin; -1 = outside every
+// window) and the weight.  Returns false when the exact path has to decide.  SYM (lo == -hi): b_(h-1-i) = -b_i, so the
+// window of -v is the mirror image of the window of v -- three classifications instead of six (the fp64 bin table is
+// symmetric to 1e-16, far inside the margin).
+template <bool SYM>
+__device__ __forceinline__ bool thr_fast_pixel(const DevParams &P, const ThrFast &F, float r, float g, float b,
+                                               int idx[6], float &iy) {
+  const float lr = fast_ln(__fadd_rn(r, kEps)), lg = fast_ln(__fadd_rn(g, kEps)), lb = fast_ln(__fadd_rn(b, kEps));
+  const float a = lr - lg, bb = lr - lb, c = lg - lb;
+  const float ar = fabsf(lr), ag = fabsf(lg), ab = fabsf(lb);
+  const float ma = fmaf(F.mrel, ar + ag, F.mt0), mb = fmaf(F.mrel, ar + ab, F.mt0), mc = fmaf(F.mrel, ag + ab, F.mt0);
+  bool unsafe = false;
+  idx[0] = thr_fast_one(F, a, ma, unsafe);
+  idx[1] = thr_fast_one(F, bb, mb, unsafe);
+  idx[3] = thr_fast_one(F, c, mc, unsafe);
+  if constexpr (SYM) {
+    const int hm = P.h - 1;
+    idx[2] = idx[0] >= 0 ? hm - idx[0] : -1;
+    idx[4] = idx[1] >= 0 ? hm - idx[1] : -1;
+    idx[5] = idx[3] >= 0 ? hm - idx[3] : -1;
+  } else {
+    idx[2] = thr_fast_one(F, -a, ma, unsafe);
+    idx[4] = thr_fast_one(F, -bb, mb, unsafe);
+    idx[5] = thr_fast_one(F, -c, mc, unsafe);
+  }
+  iy = P.intensity ? __fsqrt_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r, r), __fmul_rn(g, g)), __fmul_rn(b, b)), kEps)) : 1.f;
+  return !unsafe;
+}
+
+// the same six indices by the reference's arithmetic (fp64 logs rounded to fp32, fp64 window comparison)
+__device__ __forceinline__ void thr_exact_pixel(const DevParams &P, float r, float g, float b, double inv_step,
+                                                int idx[6], float &iy) {
+  float a, bb, c;
+  project(P, r, g, b, a, bb, c, iy);
+  idx[0] = thr_single(P, a, inv_step);   idx[1] = thr_single(P, bb, inv_step);
+  idx[2] = thr_single(P, -a, inv_step);  idx[3] = thr_single(P, c, inv_step);
+  idx[4] = thr_single(P, -bb, inv_step); idx[5] = thr_single(P, -c, inv_step);
+}
+
+// exhaustive check of the fast logarithm's error bound over every float in [1e-6, 1 + 2e-6] (the range of x + 1e-6
+// for clamped pixels): out[0] = max |__logf - ln| / |ln| over |ln x| >= 1e-3, out[1] = max absolute error elsewhere
+__global__ __launch_bounds__(256) void k_selftest_fastlog(uint32_t first, uint32_t count, unsigned int *out) {
+  float mrel = 0.f, mabs = 0.f;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count; i += gridDim.x * 256u) {
+    union { uint32_t u; float f; } cv; cv.u = first + i;
+    const float ex = (float)log((double)cv.f), fa = fast_ln(cv.f);
+    const float e = fabsf(fa - ex);
+    if (fabsf(ex) >= 1e-3f) mrel = fmaxf(mrel, e / fabsf(ex)); else mabs = fmaxf(mabs, e);
+  }
+  atomicMax(&out[0], __float_as_uint(mrel));      // non-negative floats order like their bit patterns
+  atomicMax(&out[1], __float_as_uint(mabs));
+}
+
 // ALL3: the grids of all planes are in LDS at once (3 h^2 x 8 B <= 150 KB, h <= 79): every pixel is read and projected
 // (3 fp64 logs) ONCE; otherwise plane after plane through one grid (the 2nd / 3rd read of a pixel hits L2).
 template <bool ALL3>
 __global__ __launch_bounds__(ALL3 ? 1024 : 256) void k_hist_thr_fwd(const DevParams P, const float *__restrict__ x,
-                                                                    float *__restrict__ slabs, int per_block) {
+                                                                    float *__restrict__ slabs,
+                                                                    double *__restrict__ slab_tot, int per_block) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned long long sm_tot[16];
   unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem);   // [planes][h][h]
   constexpr int NT = ALL3 ? 1024 : 256;
+  unsigned long long tot = 0ull;
   const int b = blockIdx.y, s = blockIdx.x, S = gridDim.x, h = P.h, hh = h * h;
   const float *xb = x + (long long)b * P.sb;
   const int n0 = s * per_block, n1 = min(P.npix, n0 + per_block);
@@ -941,7 +1111,11 @@ __global__ __launch_bounds__(ALL3 ? 1024 : 256) void k_hist_thr_fwd(const DevPar
       }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < P.P * hh; e += NT) slab[e] = (float)((double)bins[e] * (1.0 / kThrScale));
+    for (int e = threadIdx.x; e < P.P * hh; e += NT) {
+      const unsigned long long v = bins[e];
+      tot += v;
+      slab[e] = (float)((double)v * (1.0 / kThrScale));
+    }
   } else {
     for (int p = 0; p < 3; ++p) {
       if (P.green && p != 1) continue;
@@ -956,10 +1130,16 @@ __global__ __launch_bounds__(ALL3 ? 1024 : 256) void k_hist_thr_fwd(const DevPar
       }
       __syncthreads();
       float *dst = slab + (long long)(P.green ? 0 : p) * hh;
-      for (int e = threadIdx.x; e < hh; e += NT) dst[e] = (float)((double)bins[e] * (1.0 / kThrScale));
+      for (int e = threadIdx.x; e < hh; e += NT) {
+        const unsigned long long v = bins[e];
+        tot += v;
+        dst[e] = (float)((double)v * (1.0 / kThrScale));
+      }
       __syncthreads();
     }
   }
+  tot = block_sum_u64<NT>(tot, sm_tot);
+  if (threadIdx.x == 0) slab_tot[b * S + s] = (double)tot * (1.0 / kThrScale);
 }
 
 // Backward of the thresholding histogram: the window has zero slope, so the only path to the pixel is the weight Iy:
@@ -1001,6 +1181,222 @@ __global__ __launch_bounds__(256) void k_hist_thr_bwd(const DevParams P, const f
     for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
 }
 
+// ---- lean scatter kernels: RGB-uv, three planes, `single` windows, all three grids in LDS ----------------------------
+// The configuration every default-constructed RGBuvHistBlock(method='thresholding') has.  DIRECT: no resize and
+// contiguous planes -> 16-byte loads / stores, four pixels per thread and iteration; otherwise sample_rgb (bilinear /
+// sampling / strided input).  exact_only (HG_THR_EXACT=1) sends every pixel through the fp64 classification.
+template <bool SYM>
+__device__ __forceinline__ void thr_lean_classify(const DevParams &P, const ThrFast &F, float r, float g, float b,
+                                                  double inv_step, bool exact_only, int idx[6], float &iy) {
+  if (exact_only || !thr_fast_pixel<SYM>(P, F, r, g, b, idx, iy)) thr_exact_pixel(P, r, g, b, inv_step, idx, iy);
+}
+
+template <bool DIRECT, bool SYM>
+__global__ __launch_bounds__(1024) void k_thr_fwd_lean(const DevParams P, const float *__restrict__ x,
+                                                       float *__restrict__ slabs, double *__restrict__ slab_tot,
+                                                       float *__restrict__ hist, float *__restrict__ sum_out,
+                                                       int per_block, const bool exact_only) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned long long sm_tot[16];
+  unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem);   // [3][h][h]
+  const int b = blockIdx.y, s = blockIdx.x, S = gridDim.x, h = P.h, hh = h * h;
+  const float *xb = x + (long long)b * P.sb;
+  const int n0 = s * per_block, n1 = min(P.npix, n0 + per_block);
+  const double inv_step = 1.0 / P.step;
+  const ThrFast F = make_thr_fast(P);
+  // the first tile's loads are in flight while the grids are cleared
+  float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = r4, b4 = r4;
+  int n = n0 + 4 * threadIdx.x;
+  if (DIRECT && n < n1) {
+    r4 = *reinterpret_cast<const float4 *>(xb + n);
+    g4 = *reinterpret_cast<const float4 *>(xb + P.sc + n);
+    b4 = *reinterpret_cast<const float4 *>(xb + 2 * P.sc + n);
+  }
+  {
+    ulonglong2 *b2 = reinterpret_cast<ulonglong2 *>(bins);
+    for (int e = threadIdx.x; e < (3 * hh + 1) / 2; e += 1024) b2[e] = make_ulonglong2(0ull, 0ull);  // LDS is sized in 16-byte units
+  }
+  __syncthreads();
+  auto pixel = [&](float r, float g, float bl) __attribute__((always_inline)) {
+    int idx[6];
+    float iy;
+    thr_lean_classify<SYM>(P, F, r, g, bl, inv_step, exact_only, idx, iy);
+    const unsigned long long q = iy_fixed(iy);
+    if ((idx[0] | idx[1]) >= 0) atomicAdd(&bins[idx[0] * h + idx[1]], q);
+    if ((idx[2] | idx[3]) >= 0) atomicAdd(&bins[hh + idx[2] * h + idx[3]], q);
+    if ((idx[4] | idx[5]) >= 0) atomicAdd(&bins[2 * hh + idx[4] * h + idx[5]], q);
+  };
+  if constexpr (DIRECT) {
+    for (; n < n1; n += 4096) {
+      const float4 rc = r4, gc = g4, bc = b4;
+      if (n + 4096 < n1) {                              // next tile's loads before this tile's arithmetic
+        r4 = *reinterpret_cast<const float4 *>(xb + n + 4096);
+        g4 = *reinterpret_cast<const float4 *>(xb + P.sc + n + 4096);
+        b4 = *reinterpret_cast<const float4 *>(xb + 2 * P.sc + n + 4096);
+      }
+      pixel(clamp01(rc.x), clamp01(gc.x), clamp01(bc.x));
+      pixel(clamp01(rc.y), clamp01(gc.y), clamp01(bc.y));
+      pixel(clamp01(rc.z), clamp01(gc.z), clamp01(bc.z));
+      pixel(clamp01(rc.w), clamp01(gc.w), clamp01(bc.w));
+    }
+  } else {
+    for (int m = n0 + threadIdx.x; m < n1; m += 1024) {
+      float r, g, bl;
+      sample_rgb(P, xb, m, r, g, bl);
+      pixel(r, g, bl);
+    }
+  }
+  __syncthreads();
+  if (S == 1) {
+    // the workgroup holds the whole image: normalise here (RGBuvHistBlock.py:224-228), no slab and no k_hist_finish
+    unsigned long long t1 = 0ull;
+    for (int e = threadIdx.x; e < 3 * hh; e += 1024) t1 += bins[e];
+    t1 = block_sum_u64<1024>(t1, sm_tot);
+    const float den = (float)((double)t1 * (1.0 / kThrScale)) + kEps;
+    if (threadIdx.x == 0) sum_out[b] = den;
+    float *dst = hist + (long long)b * 3 * hh;
+    for (int e = threadIdx.x; e < 3 * hh; e += 1024) dst[e] = (float)((double)bins[e] * (1.0 / kThrScale)) / den;
+    return;
+  }
+  float *slab = slabs + ((long long)(b * S + s) * 3) * hh;
+  unsigned long long tot = 0ull;
+  const int nq = (3 * hh) >> 2;
+  if ((((uintptr_t)slab) & 15) == 0) {
+    for (int e4 = threadIdx.x; e4 < nq; e4 += 1024) {
+      const ulonglong2 v01 = reinterpret_cast<const ulonglong2 *>(bins)[2 * e4], v23 = reinterpret_cast<const ulonglong2 *>(bins)[2 * e4 + 1];
+      tot += (v01.x + v01.y) + (v23.x + v23.y);
+      reinterpret_cast<float4 *>(slab)[e4] = make_float4((float)((double)v01.x * (1.0 / kThrScale)), (float)((double)v01.y * (1.0 / kThrScale)),
+                                                         (float)((double)v23.x * (1.0 / kThrScale)), (float)((double)v23.y * (1.0 / kThrScale)));
+    }
+    for (int e = 4 * nq + threadIdx.x; e < 3 * hh; e += 1024) {
+      const unsigned long long v = bins[e];
+      tot += v;
+      slab[e] = (float)((double)v * (1.0 / kThrScale));
+    }
+  } else {
+    for (int e = threadIdx.x; e < 3 * hh; e += 1024) {
+      const unsigned long long v = bins[e];
+      tot += v;
+      slab[e] = (float)((double)v * (1.0 / kThrScale));
+    }
+  }
+  tot = block_sum_u64<1024>(tot, sm_tot);
+  if (threadIdx.x == 0) slab_tot[b * S + s] = (double)tot * (1.0 / kThrScale);
+}
+
+// One-launch backward: <G, out> is rebuilt per workgroup (2 x 48 KB from L2, as k_hist_bwd does) instead of a
+// k_hist_ghat launch + a Ghat buffer; the window has no slope, so the only path to the pixel is the weight Iy:
+// dL/dIy = sum_planes Ghat[bin] with Ghat = (G - <G,out>) / S' formed on the fly, dx_c = dL/dIy * x_c / Iy, clamp-masked.
+// Requires intensity_scale (without it the gradient is identically zero: the host clears grad_x instead).
+template <bool DIRECT, bool SYM>
+__global__ __launch_bounds__(1024) void k_thr_bwd_lean(const DevParams P, const float *__restrict__ x,
+                                                       const float *__restrict__ gout, const float *__restrict__ hist,
+                                                       const float *__restrict__ sums, float *__restrict__ gdst,
+                                                       int per_block, const bool exact_only) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float sm16[16];
+  float *gh = reinterpret_cast<float *>(smem);         // Ghat [3][h][h]: the per-pixel gathers hit LDS, not L2
+  const int b = blockIdx.y, h = P.h, hh = h * h, nel = 3 * hh;
+  const float *g = gout + (long long)b * nel, *o = hist + (long long)b * nel;
+  const float *xb = x + (long long)b * P.sb;
+  const int n0 = blockIdx.x * per_block, n1 = min(P.npix, n0 + per_block);
+  // the first tile's loads are in flight during the <G, out> prologue
+  float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = r4, b4 = r4;
+  int n = n0 + 4 * threadIdx.x;
+  if (DIRECT && n < n1) {
+    r4 = *reinterpret_cast<const float4 *>(xb + n);
+    g4 = *reinterpret_cast<const float4 *>(xb + P.sc + n);
+    b4 = *reinterpret_cast<const float4 *>(xb + 2 * P.sc + n);
+  }
+  const bool al16 = (((uintptr_t)g | (uintptr_t)o) & 15) == 0;
+  // <G, out> with every load in flight at once: a thread owns groups of four consecutive bins (16-byte loads), keeps
+  // its G values in registers, and writes Ghat = (G - <G,out>) / S' to LDS once the sum is known.  Fixed summation order.
+  constexpr int MAXQ = 5;                              // 4 * 1024 * MAXQ >= 3 h^2 for h <= 79 (the lean limit)
+  float4 gq[MAXQ];
+  float d = 0.f;
+  const int nq = nel >> 2;                             // nel = 3 h^2; when h is odd the tail (< 4 bins) is handled below
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k) {
+    const int e4 = threadIdx.x + k * 1024;
+    gq[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 oq = gq[k];
+    if (e4 < nq && al16) {
+      gq[k] = reinterpret_cast<const float4 *>(g)[e4];
+      oq = reinterpret_cast<const float4 *>(o)[e4];
+    } else if (e4 < nq) {
+      gq[k] = make_float4(g[4 * e4], g[4 * e4 + 1], g[4 * e4 + 2], g[4 * e4 + 3]);
+      oq = make_float4(o[4 * e4], o[4 * e4 + 1], o[4 * e4 + 2], o[4 * e4 + 3]);
+    }
+    d = fmaf(gq[k].x, oq.x, d); d = fmaf(gq[k].y, oq.y, d); d = fmaf(gq[k].z, oq.z, d); d = fmaf(gq[k].w, oq.w, d);
+  }
+  float gt = 0.f;
+  const int et = 4 * nq + (int)threadIdx.x;            // tail bins (nel % 4 of them)
+  if (et < nel) { gt = g[et]; d = fmaf(gt, o[et], d); }
+  d = hg_wave_sum(d);
+  if ((threadIdx.x & 63) == 0) sm16[threadIdx.x >> 6] = d;
+  __syncthreads();
+  d = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) d += sm16[w];
+  const float inv = 1.f / sums[b];
+#pragma unroll
+  for (int k = 0; k < MAXQ; ++k) {
+    const int e4 = threadIdx.x + k * 1024;
+    if (e4 < nq)
+      reinterpret_cast<float4 *>(gh)[e4] = make_float4((gq[k].x - d) * inv, (gq[k].y - d) * inv, (gq[k].z - d) * inv, (gq[k].w - d) * inv);
+  }
+  if (et < nel) gh[et] = (gt - d) * inv;
+  __syncthreads();
+  const double inv_step = 1.0 / P.step;
+  const ThrFast F = make_thr_fast(P);
+  auto pixel = [&](float r, float gg, float bl, float &dr, float &dg, float &db) __attribute__((always_inline)) {
+    int idx[6];
+    float iy;
+    thr_lean_classify<SYM>(P, F, r, gg, bl, inv_step, exact_only, idx, iy);
+    float dIy = 0.f;
+    if ((idx[0] | idx[1]) >= 0) dIy += gh[idx[0] * h + idx[1]];
+    if ((idx[2] | idx[3]) >= 0) dIy += gh[hh + idx[2] * h + idx[3]];
+    if ((idx[4] | idx[5]) >= 0) dIy += gh[2 * hh + idx[4] * h + idx[5]];
+    const float wgt = dIy / iy;
+    dr = wgt * r; dg = wgt * gg; db = wgt * bl;
+  };
+  if constexpr (DIRECT) {
+    float *gb = gdst + ((long long)b * P.C) * P.npix;
+    for (; n < n1; n += 4096) {
+      const float4 rc = r4, gc = g4, bc = b4;
+      if (n + 4096 < n1) {                              // next tile's loads before this tile's arithmetic
+        r4 = *reinterpret_cast<const float4 *>(xb + n + 4096);
+        g4 = *reinterpret_cast<const float4 *>(xb + P.sc + n + 4096);
+        b4 = *reinterpret_cast<const float4 *>(xb + 2 * P.sc + n + 4096);
+      }
+      float4 or4, og4, ob4;
+      pixel(clamp01(rc.x), clamp01(gc.x), clamp01(bc.x), or4.x, og4.x, ob4.x);
+      pixel(clamp01(rc.y), clamp01(gc.y), clamp01(bc.y), or4.y, og4.y, ob4.y);
+      pixel(clamp01(rc.z), clamp01(gc.z), clamp01(bc.z), or4.z, og4.z, ob4.z);
+      pixel(clamp01(rc.w), clamp01(gc.w), clamp01(bc.w), or4.w, og4.w, ob4.w);
+      // clamp mask of RGBuvHistBlock.py:76, decided on the raw value
+      auto m = [](float raw, float v) { return (raw >= 0.f && raw <= 1.f) ? v : 0.f; };
+      or4 = make_float4(m(rc.x, or4.x), m(rc.y, or4.y), m(rc.z, or4.z), m(rc.w, or4.w));
+      og4 = make_float4(m(gc.x, og4.x), m(gc.y, og4.y), m(gc.z, og4.z), m(gc.w, og4.w));
+      ob4 = make_float4(m(bc.x, ob4.x), m(bc.y, ob4.y), m(bc.z, ob4.z), m(bc.w, ob4.w));
+      *reinterpret_cast<float4 *>(gb + n) = or4;
+      *reinterpret_cast<float4 *>(gb + P.npix + n) = og4;
+      *reinterpret_cast<float4 *>(gb + 2LL * P.npix + n) = ob4;
+      for (int cc = 3; cc < P.C; ++cc)
+        *reinterpret_cast<float4 *>(gb + (long long)cc * P.npix + n) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    for (int m = n0 + threadIdx.x; m < n1; m += 1024) {
+      float r, gg, bl, dr, dg, db;
+      sample_rgb(P, xb, m, r, gg, bl);
+      pixel(r, gg, bl, dr, dg, db);
+      store_rgb_grad(P, xb, b, m, dr, dg, db, gdst);
+      if (P.mode == HG_RESIZE_NONE)
+        for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + m] = 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // RBF with a narrow kernel (the default sigma = 0.02 against a bin spacing of 6/63: exp(-d^2/sigma^2) is 1.4e-10 one bin
 // away): beyond R = ceil(5.26 sigma / spacing) bins the weights are < 1e-12 -- a pixel touches (2R+1)^2 bins per plane,
@@ -1017,10 +1413,13 @@ __device__ __forceinline__ int rbf_center(const DevParams &P, float u, double in
 
 template <bool ALL3>
 __global__ __launch_bounds__(ALL3 ? 1024 : 256) void k_hist_rbf_fwd(const DevParams P, const float *__restrict__ x,
-                                                                    float *__restrict__ slabs, int per_block, int R) {
+                                                                    float *__restrict__ slabs,
+                                                                    double *__restrict__ slab_tot, int per_block, int R) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ unsigned long long sm_tot[16];
   unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem);   // [planes][h][h]
   constexpr int NT = ALL3 ? 1024 : 256;
+  unsigned long long tot = 0ull;
   const int b = blockIdx.y, s = blockIdx.x, S = gridDim.x, h = P.h, hh = h * h;
   const float *xb = x + (long long)b * P.sb;
   const int n0 = s * per_block, n1 = min(P.npix, n0 + per_block);
@@ -1062,7 +1461,11 @@ __global__ __launch_bounds__(ALL3 ? 1024 : 256) void k_hist_rbf_fwd(const DevPar
       }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < P.P * hh; e += NT) slab[e] = (float)((double)bins[e] * (1.0 / kThrScale));
+    for (int e = threadIdx.x; e < P.P * hh; e += NT) {
+      const unsigned long long v = bins[e];
+      tot += v;
+      slab[e] = (float)((double)v * (1.0 / kThrScale));
+    }
   } else {
     for (int p = 0; p < 3; ++p) {
       if (P.green && p != 1) continue;
@@ -1076,10 +1479,16 @@ __global__ __launch_bounds__(ALL3 ? 1024 : 256) void k_hist_rbf_fwd(const DevPar
       }
       __syncthreads();
       float *dst = slab + (long long)(P.green ? 0 : p) * hh;
-      for (int e = threadIdx.x; e < hh; e += NT) dst[e] = (float)((double)bins[e] * (1.0 / kThrScale));
+      for (int e = threadIdx.x; e < hh; e += NT) {
+        const unsigned long long v = bins[e];
+        tot += v;
+        dst[e] = (float)((double)v * (1.0 / kThrScale));
+      }
       __syncthreads();
     }
   }
+  tot = block_sum_u64<NT>(tot, sm_tot);
+  if (threadIdx.x == 0) slab_tot[b * S + s] = (double)tot * (1.0 / kThrScale);
 }
 
 // Backward of the truncated RBF histogram: the generic backward's two mat-vecs per plane restricted to the (2R+1)^2
@@ -1250,6 +1659,29 @@ inline int rbf_radius(const hg_hist_params *p) {
 
 inline bool sparse_path(const hg_hist_params *p) { return thr_scatter(p) || rbf_radius(p) > 0; }
 
+// HG_THR_EXACT=1: every window decision by the fp64 path (A/B switch of the fast classification)
+inline bool thr_exact_only() {
+  if (const char *e = getenv("HG_THR_EXACT")) return atoi(e) != 0;
+  return false;
+}
+
+// The lean scatter kernels (k_thr_fwd_lean / k_thr_bwd_lean) apply to: RGB-uv, three planes, `single` windows (narrower
+// than the bin spacing: every symmetric boundary), all three 64-bit grids in LDS at once (h <= 79).
+inline bool thr_lean(const hg_hist_params *p) {
+  if (!thr_scatter(p) || p->projection != HG_PROJ_RGBUV || p->green_only || p->h < 2) return false;
+  if ((size_t)3 * p->h * p->h * 8 > 150 * 1024) return false;
+  const double step = (p->hi - p->lo) / (double)(p->h - 1);
+  const double half_eps = ((p->lo < 0 ? -p->lo : p->lo) + (p->hi < 0 ? -p->hi : p->hi)) / (double)p->h / 2.0;
+  return step > 2.0 * half_eps * (1.0 + 1e-9);
+}
+
+// no resize, contiguous planes, 16-byte aligned rows of four pixels: the float4 variant
+inline bool thr_direct(const hg_hist_params *p, const float *x, const float *gx) {
+  const long long npix = (long long)p->H * p->W;
+  return p->resize_mode == HG_RESIZE_NONE && p->stride_w == 1 && p->stride_h == p->W && (npix & 3) == 0 &&
+         (p->stride_c & 3) == 0 && (p->stride_b & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)gx & 15) == 0;
+}
+
 // Which backward kernel?  0: k_hist_bwd (symmetric boundary, h <= 64, RGB-uv) or, for thresholding beyond the scatter
 // path / h > 128, k_hist_bwd_generic.  RT > 0: k_hist_bwd_planes<RT> -- smooth kernels with an asymmetric boundary,
 // 64 < h <= 128, or a one-plane projection.  HG_BWD_PLANES=1 sends the symmetric h <= 64 case there too (A/B runs,
@@ -1288,6 +1720,8 @@ Plan make_plan(const hg_hist_params *p) {
   pl.nparts = (int)((n_per_img + 1023) / 1024);
   pl.slab_bytes = (size_t)p->B * S * n_per_img * sizeof(float);
   pl.part_bytes = ((size_t)p->B * pl.nparts * sizeof(float) + 255) / 256 * 256;
+  if (sparse_path(p))   // slab_tot[B][S] doubles (k_hist_finish) instead of the per-block float partials
+    pl.part_bytes = ((size_t)p->B * S * sizeof(double) + 255) / 256 * 256;
   // backward: 1 workgroup per CU, rounds of 32 pixels per wave
   const long long rounds_total = (npix + 31) / 32;
   long long targetb = 512;
@@ -1430,6 +1864,18 @@ const char *hg_error_string(int code) {
   }
 }
 
+int hg_selftest_fastlog(float *out2, void *stream) {
+  if (!out2) return HG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out2, 0, 2 * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  union { float f; uint32_t u; } a, b;
+  a.f = 1e-6f; b.f = 1.000002f;
+  hipLaunchKernelGGL(k_selftest_fastlog, dim3(2048), dim3(256), 0, st, a.u, b.u - a.u + 1u, (unsigned int *)out2);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
 int hg_rgbuv_hist_workspace_bytes(const hg_hist_params *p, size_t *fwd_bytes, size_t *bwd_bytes) {
   const int rc = validate(p);
   if (rc) return rc;
@@ -1454,7 +1900,7 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
   if (sparse_path(p)) {
     const size_t one = (size_t)d.h * d.h * sizeof(unsigned long long);
     const bool all3 = one * d.P <= 150 * 1024;
-    const size_t lds = all3 ? one * d.P : one;
+    const size_t lds = ((all3 ? one * d.P : one) + 15) / 16 * 16;
     const int R = rbf_radius(p);
     const void *kern = R ? (all3 ? (const void *)k_hist_rbf_fwd<true> : (const void *)k_hist_rbf_fwd<false>)
                          : (all3 ? (const void *)k_hist_thr_fwd<true> : (const void *)k_hist_thr_fwd<false>);
@@ -1463,14 +1909,32 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
       if (e != hipSuccess) return (int)e;
     }
     const dim3 grid(pl.S_fwd, d.B), block(all3 ? 1024 : 256);
+    double *slab_tot = (double *)workspace;
     if (R) {
-      if (all3) hipLaunchKernelGGL(k_hist_rbf_fwd<true>, grid, block, lds, st, d, x, slabs, 4 * pl.chunk, R);
-      else hipLaunchKernelGGL(k_hist_rbf_fwd<false>, grid, block, lds, st, d, x, slabs, 4 * pl.chunk, R);
+      if (all3) hipLaunchKernelGGL(k_hist_rbf_fwd<true>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk, R);
+      else hipLaunchKernelGGL(k_hist_rbf_fwd<false>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk, R);
+    } else if (thr_lean(p)) {
+      const bool ex = thr_exact_only(), dir = thr_direct(p, x, x);
+      const void *lk = dir ? (sym ? (const void *)k_thr_fwd_lean<true, true> : (const void *)k_thr_fwd_lean<true, false>)
+                           : (sym ? (const void *)k_thr_fwd_lean<false, true> : (const void *)k_thr_fwd_lean<false, false>);
+      if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(lk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+      }
+      if (dir && sym) hipLaunchKernelGGL((k_thr_fwd_lean<true, true>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
+      else if (dir) hipLaunchKernelGGL((k_thr_fwd_lean<true, false>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
+      else if (sym) hipLaunchKernelGGL((k_thr_fwd_lean<false, true>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
+      else hipLaunchKernelGGL((k_thr_fwd_lean<false, false>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
     } else {
-      if (all3) hipLaunchKernelGGL(k_hist_thr_fwd<true>, grid, block, lds, st, d, x, slabs, 4 * pl.chunk);
-      else hipLaunchKernelGGL(k_hist_thr_fwd<false>, grid, block, lds, st, d, x, slabs, 4 * pl.chunk);
+      if (all3) hipLaunchKernelGGL(k_hist_thr_fwd<true>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk);
+      else hipLaunchKernelGGL(k_hist_thr_fwd<false>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk);
     }
     HG_LAUNCH_CHECK();
+    if (!R && thr_lean(p) && pl.S_fwd == 1) return HG_OK;          // normalised in the scatter kernel
+    hipLaunchKernelGGL(k_hist_finish, dim3(pl.nparts, d.B), dim3(256), 0, st, slabs, slab_tot, hist_out, sum_out,
+                       pl.S_fwd, d.P * d.h * d.h);
+    HG_LAUNCH_CHECK();
+    return HG_OK;
   } else {
     int r = (pl.T == 1) ? launch_fwd_t<1>(d, pl, sym, x, slabs, st) : launch_fwd_t<2>(d, pl, sym, x, slabs, st);
     if (r) return r;
@@ -1504,7 +1968,26 @@ int hg_rgbuv_hist_bwd(const hg_hist_params *p, const float *x, const float *grad
       if (e != hipSuccess) return (int)e;
     }
   }
-  if (sparse_path(p)) {
+  if (thr_lean(p) && !p->intensity_scale && d.mode == HG_RESIZE_NONE) {
+    // a 0/1 window has no slope and there is no weight to differentiate: the gradient is identically zero
+    hipError_t e = hipMemsetAsync(grad_x, 0, gx_bytes, st);
+    if (e != hipSuccess) return (int)e;
+  } else if (thr_lean(p) && p->intensity_scale) {
+    const bool ex = thr_exact_only(), dir = thr_direct(p, x, grad_x);
+    const dim3 grid(pl.S_fwd, d.B), block(1024);
+    const size_t blds = (size_t)3 * d.h * d.h * sizeof(float);
+    if (blds > 48 * 1024) {
+      const void *lk = dir ? (sym ? (const void *)k_thr_bwd_lean<true, true> : (const void *)k_thr_bwd_lean<true, false>)
+                           : (sym ? (const void *)k_thr_bwd_lean<false, true> : (const void *)k_thr_bwd_lean<false, false>);
+      hipError_t e = hipFuncSetAttribute(lk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)blds);
+      if (e != hipSuccess) return (int)e;
+    }
+    if (dir && sym) hipLaunchKernelGGL((k_thr_bwd_lean<true, true>), grid, block, blds, st, d, x, grad_out, hist_out, sum_out, gdst, 4 * pl.chunk, ex);
+    else if (dir) hipLaunchKernelGGL((k_thr_bwd_lean<true, false>), grid, block, blds, st, d, x, grad_out, hist_out, sum_out, gdst, 4 * pl.chunk, ex);
+    else if (sym) hipLaunchKernelGGL((k_thr_bwd_lean<false, true>), grid, block, blds, st, d, x, grad_out, hist_out, sum_out, gdst, 4 * pl.chunk, ex);
+    else hipLaunchKernelGGL((k_thr_bwd_lean<false, false>), grid, block, blds, st, d, x, grad_out, hist_out, sum_out, gdst, 4 * pl.chunk, ex);
+    HG_LAUNCH_CHECK();
+  } else if (sparse_path(p)) {
     float *gh = (float *)((char *)workspace + pl.gxs_bytes);
     hipLaunchKernelGGL(k_hist_ghat, dim3(d.B), dim3(1024), 0, st, grad_out, hist_out, sum_out, gh, d.P * d.h * d.h);
     HG_LAUNCH_CHECK();

@@ -70,6 +70,13 @@ typedef struct hg_hist_params {
 int hg_version(void);
 const char *hg_error_string(int code);
 
+/* Self-test of the scatter path's fast window classification (method = thresholding): exhaustive error of the
+ * hardware logarithm it uses over every float in [1e-6, 1 + 2e-6], against the fp64 logarithm rounded to fp32 that
+ * the exact path (and the reference's CPU logf, RGBuvHistBlock.py:112-114) evaluates.  out2 (device, 2 floats):
+ * [0] = max relative error where |ln x| >= 1e-3, [1] = max absolute error elsewhere.  The classification's margins
+ * assume [0] <= 3e-7 and [1] <= 3e-7 (hg_hist.hip: kFastLogRel, kFastAbs carry the roundings on top). */
+int hg_selftest_fastlog(float *out2, void *stream);
+
 /* Bytes of scratch each call needs for these params (both may be queried at once). */
 int hg_rgbuv_hist_workspace_bytes(const hg_hist_params *p, size_t *fwd_bytes, size_t *bwd_bytes);
 

@@ -228,3 +228,38 @@ def test_plane_backward_matches_merged_backward(h, method, sigma, gpu_device, mo
     xb = x.to(gpu_device).requires_grad_(True)
     blk(xb).backward(go)
     assert relmax(xb.grad.cpu().numpy(), xa.grad.cpu().numpy()) <= 1e-5
+
+
+def test_fast_window_classification_is_exact(gpu_device, monkeypatch):
+    """method='thresholding': the scatter kernels decide window membership with the hardware logarithm + an explicit
+    error margin and fall back to the fp64 path inside the margin.  (i) the logarithm's error bound the margins assume,
+    measured exhaustively over the input range; (ii) histograms and gradients bit-identical to the all-exact path
+    (HG_THR_EXACT=1) on 2.1 M pixels incl. saturated / dark / constant regions."""
+    import ctypes
+    from histogan_amd._lib import check, lib
+    out2 = torch.zeros(2, device=gpu_device)
+    check(lib.hg_selftest_fastlog(out2.data_ptr(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'selftest')
+    rel, ab = out2.cpu().tolist()
+    print(f'fast log: max rel err {rel:.3e} (|ln x| >= 1e-3), max abs err {ab:.3e} (near x = 1)')
+    assert rel <= 3.0e-7 and ab <= 3.0e-7          # margins: 3.6e-7 relative, 9e-7 absolute (incl. the bin arithmetic's roundings)
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(32, 3, 256, 256, generator=g)
+    x[0] = torch.rand(3, 256, 256, generator=g) * 0.01               # dark image: |ln x| large
+    x[1] = 1.0 - torch.rand(3, 256, 256, generator=g) * 1e-3         # near-saturated: ln x ~ 0
+    x[2, :, :128] = 0.0; x[2, :, 128:] = 1.0
+    x[3] = torch.rand(3, 1, 1, generator=g)                          # constant colour
+    x[4] = (torch.rand(3, 256, 256, generator=g) * 255).round() / 255  # 8-bit image values
+    for kw in (dict(h=64, insz=256), dict(h=64, insz=150), dict(h=32, insz=256, green_only=True)):
+        blk = _block(dict(method='thresholding', **kw))
+        go = None
+        res = []
+        for exact in ('0', '1'):
+            monkeypatch.setenv('HG_THR_EXACT', exact)
+            xg = x.to(gpu_device).requires_grad_(True)
+            out = blk(xg)
+            if go is None:
+                go = torch.randn(out.shape, generator=g).to(gpu_device)
+            out.backward(go)
+            res.append((out.detach().clone(), xg.grad.clone()))
+        assert torch.equal(res[0][0], res[1][0])
+        assert torch.equal(res[0][1], res[1][1])
