@@ -75,6 +75,10 @@ def _load():
     lib.hg_demod_noise_lrelu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]
     lib.hg_diffgrad_step.restype = ctypes.c_int
     lib.hg_diffgrad_step.argtypes = [vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp]
+    lib.hg_diffgrad_step_size.restype = f32
+    lib.hg_diffgrad_step_size.argtypes = [f32, f32, f32, i32]
+    lib.hg_diffgrad_step_dev.restype = ctypes.c_int
+    lib.hg_diffgrad_step_dev.argtypes = [vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, vp]
     lib.hg_ema_update.restype = ctypes.c_int
     lib.hg_ema_update.argtypes = [vp, vp, i64, f32, vp]
     # include/hg_conv.h
@@ -131,7 +135,7 @@ lib = _load()
 EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_fwd',
            'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd', 'hg_selftest_fastlog',
            'hg_modulate_fwd', 'hg_modulate_bwd', 'hg_demod_noise_lrelu_fwd', 'hg_demod_noise_lrelu_bwd',
-           'hg_diffgrad_step', 'hg_ema_update', 'hg_nets_workspace_bytes', 'hg_channel_sum',
+           'hg_diffgrad_step', 'hg_diffgrad_step_size', 'hg_diffgrad_step_dev', 'hg_ema_update', 'hg_nets_workspace_bytes', 'hg_channel_sum',
            'hg_conv_packed_elems', 'hg_conv_pack_weights', 'hg_conv_pack_weights_both', 'hg_conv2d_fwd', 'hg_modconv2d_fwd', 'hg_conv2d_workspace_bytes', 'hg_conv2d_dgrad',
            'hg_conv2d_wgrad_workspace_bytes',
            'hg_conv2d_wgrad', 'hg_conv_b6_packed_bytes', 'hg_conv_b6_pack_weights', 'hg_conv2d_b6',

@@ -233,6 +233,7 @@ def conv_wgrad(x, gout, ksize, stride=1, iscale=None, gscale=None, out=None):
 # step (gradient accumulation, the gradient penalty's second-order term, the path-length pass) is simply added there;
 # FlatParams.gather() makes the main stream wait for the side stream before anything reads the buffer.
 SIDE_WGRAD = os.environ.get('HG_WGRAD_STREAM', '1') != '0'
+GRAPH_WGRAD_INLINE = os.environ.get('HG_GRAPH_WGRAD_INLINE', '1') != '0'
 _slots = {}          # (data_ptr, shape) of a registered weight -> (offset, numel, weakref to the owner FlatParams)
 _side_streams = {}   # device index -> torch.cuda.Stream
 
@@ -277,10 +278,19 @@ def _direct_wgrad(w, x, g, stride):
     xc, gc = _f32c(x), _f32c(g)
     if _batch_pieces(xc, w, stride) != 1:
         return False
+    skey = slot.data_ptr()
+    if GRAPH_WGRAD_INLINE and torch.cuda.is_current_stream_capturing():
+        # inside a hipGraph capture every fork to the side stream becomes a cross-branch dependency edge (~100 per step):
+        # measured slower than the eager side stream; the direct write (no per-parameter copy) stays, on the main branch
+        if skey in flat.direct_written:
+            slot.add_(conv_wgrad(xc, gc, w.shape[2], stride))
+        else:
+            conv_wgrad(xc, gc, w.shape[2], stride, out=slot)
+            flat.direct_written.add(skey)
+        return True
     main = torch.cuda.current_stream(x.device)
     side = side_stream(x.device)
     side.wait_event(main.record_event())             # g (and x) are ready on the main stream
-    skey = slot.data_ptr()
     with torch.cuda.stream(side):
         if skey in flat.direct_written:
             slot.add_(conv_wgrad(xc, gc, w.shape[2], stride))

@@ -322,6 +322,24 @@ __global__ __launch_bounds__(256) void k_diffgrad(float *__restrict__ p, const f
   }
 }
 
+// the same update with the bias-corrected step size read from device memory: the launch carries no per-step host
+// value, so it can live in a captured hipGraph (the host refreshes *step_size_dev before each replay)
+__global__ __launch_bounds__(256) void k_diffgrad_dev(float *__restrict__ p, const float *__restrict__ g,
+                                                      float *__restrict__ m, float *__restrict__ v,
+                                                      float *__restrict__ pg, long long n,
+                                                      const float *__restrict__ step_size_dev, float b1, float b2,
+                                                      float eps) {
+  const float step_size = *step_size_dev;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float dfc = 1.f / (1.f + expf(-fabsf(pg[i] - gi)));
+    m[i] = mi; v[i] = vi; pg[i] = gi;
+    p[i] -= step_size * (mi * dfc) / (sqrtf(vi) + eps);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_ema(float *__restrict__ ma, const float *__restrict__ p, long long n,
                                              float beta) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
@@ -444,6 +462,20 @@ int hg_diffgrad_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq
   const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
   hipLaunchKernelGGL(k_diffgrad, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq,
                      prev_grad, (long long)n, step_size, beta1, beta2, eps);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+float hg_diffgrad_step_size(float lr, float beta1, float beta2, int32_t step) {
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  return (float)((double)lr * sqrt(bc2) / bc1);
+}
+
+int hg_diffgrad_step_dev(float *p, const float *g, float *exp_avg, float *exp_avg_sq, float *prev_grad, int64_t n,
+                         const float *step_size_dev, float beta1, float beta2, float eps, void *stream) {
+  if (!p || !g || !exp_avg || !exp_avg_sq || !prev_grad || !step_size_dev || n <= 0) return HG_EINVAL;
+  hipLaunchKernelGGL(k_diffgrad_dev, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, exp_avg, exp_avg_sq,
+                     prev_grad, (long long)n, step_size_dev, beta1, beta2, eps);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }

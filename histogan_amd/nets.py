@@ -381,7 +381,7 @@ class Discriminator(nn.Module):
         self.to_logit = nn.Linear(2 * 2 * filters[-1], 1)
 
     def forward(self, x):
-        quantize_loss = torch.zeros(1).to(x)
+        quantize_loss = torch.zeros(1, device=x.device, dtype=x.dtype)
         for block, attn_block, q_block in zip(self.blocks, self.attn_blocks, self.quantize_blocks):
             x = block(x)
             if attn_block is not None:

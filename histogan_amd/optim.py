@@ -67,8 +67,9 @@ class FlatParams:
             return
         self.direct_ok = False
         if self.direct_written and self.grad.is_cuda:   # weight gradients written on the side stream: order them before any reader
-            from .conv import side_stream
-            torch.cuda.current_stream(self.grad.device).wait_stream(side_stream(self.grad.device))
+            from .conv import GRAPH_WGRAD_INLINE, side_stream
+            if not (GRAPH_WGRAD_INLINE and torch.cuda.is_current_stream_capturing()):   # (captured: written on this branch)
+                torch.cuda.current_stream(self.grad.device).wait_stream(side_stream(self.grad.device))
         dst, src, missing, both = [], [], [], []
         off = 0
         base = self.grad.data_ptr()
@@ -102,6 +103,8 @@ class DiffGrad:
         self.flat = params if isinstance(params, FlatParams) else FlatParams(params)
         self.lr, self.betas, self.eps = lr, betas, eps
         self.step_count = 0
+        self.graph_mode = False
+        self._step_size_dev = None
         z = lambda: torch.zeros_like(self.flat.data)
         self.exp_avg, self.exp_avg_sq, self.previous_grad = z(), z(), z()
         self.param_groups = [{'params': self.flat.params, 'lr': lr, 'betas': betas, 'eps': eps}]
@@ -109,11 +112,30 @@ class DiffGrad:
     def zero_grad(self, set_to_none=False):
         self.flat.zero_grad()
 
+    def prepare_replay(self):
+        """Graph mode (the train step captured as a hipGraph): advance the step counter on the host and refresh the
+        bias-corrected step size the captured launch reads from device memory.  Call once per replay, before it."""
+        self.step_count += 1
+        if self._step_size_dev is None:
+            self._step_size_dev = torch.zeros((), dtype=torch.float32, device=self.flat.data.device)
+        lr = self.param_groups[0]['lr']
+        self._step_size_dev.fill_(lib.hg_diffgrad_step_size(float(lr), float(self.betas[0]), float(self.betas[1]),
+                                                            self.step_count))
+
     def step(self):
         f = self.flat
         f.gather()
         if not f.data.is_cuda:
             raise RuntimeError('DiffGrad: parameters are not on a GPU; no CPU implementation')
+        if self.graph_mode:           # being captured: step size from device memory, counter advanced by prepare_replay()
+            with torch.cuda.device(f.data.device):
+                check(lib.hg_diffgrad_step_dev(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                               self.exp_avg_sq.data_ptr(), self.previous_grad.data_ptr(), f.numel,
+                                               self._step_size_dev.data_ptr(), float(self.betas[0]),
+                                               float(self.betas[1]), float(self.eps), _st(f.data)),
+                      'hg_diffgrad_step_dev')
+            weights_changed(f.data)
+            return
         self.step_count += 1
         lr = self.param_groups[0]['lr']
         with torch.cuda.device(f.data.device):

@@ -21,6 +21,7 @@ from math import floor, log2
 from pathlib import Path
 from random import random
 from shutil import rmtree
+from time import perf_counter
 
 import numpy as np
 import torch
@@ -38,6 +39,13 @@ from .optim import DiffGrad, FlatParams, ema_update
 EPS = 1e-8
 EXTS = ['jpg', 'png']
 G_OVERLAP = os.environ.get('HG_G_OVERLAP', '1') != '0'   # G-phase generator forward on a second stream beside the D phase
+# Plain steps replayed from a captured hipGraph (single process): HG_GRAPH = auto (default) | 1 | 0 | 2.
+#   auto: decided from the first eager plain steps -- the graph is used when the host's enqueue work is the larger part
+#         of the step (small batches, slow hosts: batch 4 at 256^2 runs 30 -> 20 ms); a GPU-bound step stays eager, where
+#         the side-stream overlaps (conv.py, `_g_stream`) are worth 2-3 % that a replayed multi-branch graph does not keep.
+#   2:    the static-input step WITHOUT capture (A/B of the replay: identical parameter checksums, tools/graph_probe.py)
+GRAPH_MODE = os.environ.get('HG_GRAPH', 'auto')
+GRAPH_AUTO_RATIO = float(os.environ.get('HG_GRAPH_AUTO_RATIO', '0.6'))
 
 
 class NanException(Exception):
@@ -284,6 +292,7 @@ class Trainer():
         self.pl_length_ma = EMA(0.99)
         self.device = torch.device('cuda', torch.cuda.current_device())
         self.rng = _Rng(self.device, rng)
+        self.graph_mode = GRAPH_MODE          # 'auto' | '1' | '0' | '2' (see GRAPH_MODE above)
         self.is_main = ddp.rank() == 0
         self.run_evaluate = True      # benchmarks switch evaluate()/save() off (excluded from the metric)
         self.run_save = True
@@ -344,15 +353,107 @@ class Trainer():
         h_w_space = torch.cat((h_w_space, h_w_space), dim=1)
         return styles_def_to_tensor(w_space), h_w_space
 
-    def train(self, alpha=2):
-        assert self.loader is not None, ('You must first initialize the data source with '
-                                         '`.set_data_src(<folder of images>)` or `.set_synthetic_data_src()`')
-        torch.autograd.set_detect_anomaly(False)
-        if self.GAN is None:
-            self.init_GAN()
+    # ------------------------------------------------------------------------------------------
+    # hipGraph replay of the plain step (no gradient penalty, no path-length term: 23 of every 32 steps)
+    def _graph_eligible(self, apply_gradient_penalty, apply_path_penalty):
+        """The step's ~1 800 launches cost the host ~45 ms of enqueue work; a captured graph replays them with one call.
+        Captured: the plain step of a single-process run without DiffAugment / feature quantisation / gradient
+        accumulation (those draw host-side random tables, keep batch-dependent buffers or change the launch sequence).
+        HG_GRAPH=0 switches it off."""
+        if self.graph_mode == '0' or apply_gradient_penalty or apply_path_penalty or ddp.is_dist():
+            return False
+        if self.gradient_accumulate_every != 1 or self.aug_prob > 0.0 or self.rng.mode != 'device':
+            return False
+        if any(q is not None for q in self.GAN.D.quantize_blocks) or getattr(self, '_graph_failed', False):
+            return False
+        if self.steps < getattr(self, '_graph_from', 6):          # a few eager steps first: caches, workspaces, gc freeze
+            return False
+        if self.graph_mode == 'auto':
+            use = getattr(self, '_graph_auto', None)
+            if use is None:
+                r = sorted(getattr(self, '_host_ratio', []))
+                if len(r) < 3:
+                    return False
+                use = self._graph_auto = r[len(r) // 2] > GRAPH_AUTO_RATIO
+            return use
+        return True
+
+    def _graph_inputs(self):
+        """Static buffers the captured step reads: the D phase's batch, the G phase's target histograms, and the two
+        style-mixing split points (layers styled by the first latent; all of them = no mixing)."""
+        gs = getattr(self, '_gs', None)
+        if gs is None:
+            b = next(self.loader)
+            dev = self.device
+            gs = self._gs = dict(images=torch.empty_like(b['images']), hist_d=torch.empty_like(b['histograms']),
+                                 hist_g=torch.empty_like(b['histograms']),
+                                 tt_d=torch.zeros((), dtype=torch.int64, device=dev),
+                                 tt_g=torch.zeros((), dtype=torch.int64, device=dev))
+            self._gs_first = b
+        return gs
+
+    def _fill_graph_inputs(self, gs):
+        layers = self.GAN.G.num_layers - 2
+        b = self.__dict__.pop('_gs_first', None) or next(self.loader)
+        gs['images'].copy_(b['images'], non_blocking=True)
+        gs['hist_d'].copy_(b['histograms'], non_blocking=True)
+        gs['hist_g'].copy_(next(self.loader)['histograms'], non_blocking=True)
+        mixed = random() < self.mixed_prob         # one choice per step (reference :891), a fresh split point per phase (:936)
+        for key in ('tt_d', 'tt_g'):
+            gs[key].fill_(int(torch.rand(()).numpy() * layers) if mixed else layers)
+
+    def _latents_static(self, tt_dev, batch_size, layers, latent_dim):
+        """Style tensor (B, layers, 512) with a DEVICE-side split point: layers < tt from latent 1, the rest from latent 2
+        (`styles_def_to_tensor(latent_to_w(S, mixed_list(...)))` of the reference, :166-189, with the launch sequence
+        independent of the draw)."""
+        w1 = self.GAN.S(self.rng.noise(batch_size, latent_dim))
+        w2 = self.GAN.S(self.rng.noise(batch_size, latent_dim))
+        first = (torch.arange(layers, device=self.device) < tt_dev).view(1, layers, 1)
+        return torch.where(first, w1[:, None, :], w2[:, None, :])
+
+    def _graphed_step(self, alpha):
         GAN = self.GAN
-        GAN.train()
-        _freeze_gc_once(self)
+        gs = self._graph_inputs()
+        self._fill_graph_inputs(gs)
+        GAN.D_opt.prepare_replay()
+        GAN.G_opt.prepare_replay()
+        if self.graph_mode == '2':             # HG_GRAPH=2: the static-input step WITHOUT capture (A/B of the replay)
+            for o in (GAN.D_opt, GAN.G_opt):
+                o.graph_mode = True
+            stats = self._device_step(alpha, False, False, gs)
+            for o in (GAN.D_opt, GAN.G_opt):
+                o.graph_mode = False
+            return stats
+        if getattr(self, '_graph', None) is None:
+            weights_changed()                  # every packed operand the step reads must be produced INSIDE the graph
+            for o in (GAN.D_opt, GAN.G_opt):
+                o.graph_mode = True
+            graph = torch.cuda.CUDAGraph()
+            try:
+                torch.cuda.synchronize()
+                with torch.cuda.graph(graph):
+                    stats = self._device_step(alpha, False, False, gs)
+            except Exception as e:             # capture refused (driver / library limitation): stay eager
+                for o in (GAN.D_opt, GAN.G_opt):
+                    o.graph_mode = False
+                    o.step_count -= 1
+                self._graph_failed = True
+                torch.cuda.synchronize()
+                print(f'hipGraph capture of the train step failed ({type(e).__name__}: {e}); running eagerly')
+                weights_changed()
+                return self._device_step(alpha, False, False, None)
+            for o in (GAN.D_opt, GAN.G_opt):
+                o.graph_mode = False
+            self._graph, self._graph_stats = graph, stats
+        self._graph.replay()
+        weights_changed()                      # eager steps in between must not trust operands packed by the graph
+        return self._graph_stats
+
+    def _device_step(self, alpha, apply_gradient_penalty, apply_path_penalty, gs=None):
+        """All device work of one optimisation step (reference :853-989), no host synchronisation.  gs: static input
+        buffers when the step is being captured as a hipGraph (None: eager).  Returns the stacked statistics
+        [D loss, G loss, histogram loss, gradient penalty, quantize loss, path length]."""
+        GAN = self.GAN
         dev = self.device
         zero = lambda: torch.zeros((), device=dev)
         total_disc_loss, total_gen_loss, total_hist_loss = zero(), zero(), zero()
@@ -364,19 +465,27 @@ class Trainer():
         num_layers = GAN.G.num_layers
         Disc = GAN.D
         acc = self.gradient_accumulate_every
-        apply_gradient_penalty = self.steps % 4 == 0
-        apply_path_penalty = self.steps % 32 == 0
         has_vq = any(q is not None for q in Disc.quantize_blocks)
         # DiffAugment of everything the discriminator sees (reference :873-878, 905-908, 950-951)
         aug = (lambda im, detach=False: GAN.D_aug.augment(im, prob=self.aug_prob, types=self.aug_types, detach=detach)
                ) if self.aug_prob > 0.0 else (lambda im, detach=False: im)
 
+        def w_and_hw_static(tt_key, hist_batch):
+            w_styles = self._latents_static(gs[tt_key], batch_size, num_layers - 2, latent_dim)
+            h_w_space = torch.unsqueeze(GAN.H(hist_batch), dim=1)
+            return w_styles, torch.cat((h_w_space, h_w_space), dim=1)
+
         def g_forward():
             """latents, noise, target histograms and the generator forward of the G phase (reference :937-949)"""
-            style = get_latents_fn(batch_size, num_layers - 2, latent_dim)
-            noise = self.rng.image_noise(batch_size, image_size)
-            hist_batch = next(self.loader)['histograms'].to(dev)
-            w_styles, h_w_space = self._w_and_hw(style, hist_batch)
+            if gs is None:
+                style = get_latents_fn(batch_size, num_layers - 2, latent_dim)
+                noise = self.rng.image_noise(batch_size, image_size)
+                hist_batch = next(self.loader)['histograms'].to(dev)
+                w_styles, h_w_space = self._w_and_hw(style, hist_batch)
+            else:
+                hist_batch = gs['hist_g']
+                w_styles, h_w_space = w_and_hw_static('tt_g', hist_batch)
+                noise = self.rng.image_noise(batch_size, image_size)
             return noise, hist_batch, w_styles, h_w_space, GAN.G(w_styles, h_w_space, noise)
 
         # (single-GPU runs only: under data parallelism the D-gradient all-reduce hides behind the G-phase forward instead)
@@ -393,15 +502,23 @@ class Trainer():
         # ---- discriminator phase (reference :889-932)
         GAN.D_opt.zero_grad()
         for i in range(acc):
-            get_latents_fn = self.rng.mixed_list if random() < self.mixed_prob else self.rng.noise_list
-            style = get_latents_fn(batch_size, num_layers - 2, latent_dim)
-            noise = self.rng.image_noise(batch_size, image_size)
-            batch = next(self.loader)
-            # d D(real) / d images is only needed by the gradient penalty (the reference sets requires_grad always, :897)
-            image_batch = batch['images'].to(dev).detach().requires_grad_(apply_gradient_penalty)
-            hist_batch = batch['histograms'].to(dev)
+            if gs is None:
+                get_latents_fn = self.rng.mixed_list if random() < self.mixed_prob else self.rng.noise_list
+                style = get_latents_fn(batch_size, num_layers - 2, latent_dim)
+                noise = self.rng.image_noise(batch_size, image_size)
+                batch = next(self.loader)
+                # d D(real) / d images is only needed by the gradient penalty (the reference sets requires_grad always, :897)
+                image_batch = batch['images'].to(dev).detach().requires_grad_(apply_gradient_penalty)
+                hist_batch = batch['histograms'].to(dev)
+            else:
+                get_latents_fn = None
+                image_batch, hist_batch = gs['images'], gs['hist_d']
             with torch.no_grad():   # the reference detaches this output; no graph is needed
-                w_styles, h_w_space = self._w_and_hw(style, hist_batch)
+                if gs is None:
+                    w_styles, h_w_space = self._w_and_hw(style, hist_batch)
+                else:
+                    w_styles, h_w_space = w_and_hw_static('tt_d', hist_batch)
+                    noise = self.rng.image_noise(batch_size, image_size)
                 generated_images = GAN.G(w_styles, h_w_space, noise)
             if overlap_g:
                 # The generator forward of the G phase depends on nothing the D phase produces (same generator
@@ -480,9 +597,31 @@ class Trainer():
         GAN._reduce_g()
         GAN.G_opt.step()
 
+        return torch.stack([total_disc_loss, total_gen_loss, total_hist_loss, gp_val.reshape(()),
+                            q_val.reshape(()), pl_len if pl_len is not None else zero()]).double()
+
+    def train(self, alpha=2):
+        assert self.loader is not None, ('You must first initialize the data source with '
+                                         '`.set_data_src(<folder of images>)` or `.set_synthetic_data_src()`')
+        torch.autograd.set_detect_anomaly(False)
+        if self.GAN is None:
+            self.init_GAN()
+        GAN = self.GAN
+        GAN.train()
+        _freeze_gc_once(self)
+        t_host0 = perf_counter()
+        apply_gradient_penalty = self.steps % 4 == 0
+        apply_path_penalty = self.steps % 32 == 0
+        if self._graph_eligible(apply_gradient_penalty, apply_path_penalty):
+            stats = self._graphed_step(alpha)
+        else:
+            stats = self._device_step(alpha, apply_gradient_penalty, apply_path_penalty, None)
+
         # ---- one read-back for everything the host needs (reference: >= 7 syncs)
-        stats = torch.stack([total_disc_loss, total_gen_loss, total_hist_loss, gp_val.reshape(()),
-                             q_val.reshape(()), pl_len if pl_len is not None else zero()]).double()
+        # host time spent enqueueing this step (everything before the one blocking read-back); graphed: the replay call
+        self.host_enqueue_ms = (perf_counter() - t_host0) * 1e3
+        self.last_step_graphed = getattr(self, '_graph', None) is not None and not (apply_gradient_penalty or apply_path_penalty)
+        self._t_host0 = t_host0
         if ddp.is_dist():
             nan_flag = torch.isnan(stats[:2]).any().double().reshape(1)
             packed = torch.cat([stats, nan_flag])
@@ -494,6 +633,10 @@ class Trainer():
         else:
             host = stats.cpu().numpy()
             has_nan = bool(np.isnan(host[:2]).any())
+        if self.graph_mode == 'auto' and getattr(self, '_graph_auto', None) is None and self.steps >= 2 \
+                and not (apply_gradient_penalty or apply_path_penalty):
+            # eager plain step: share of its wall time (up to the read-back's return) the host spent enqueueing
+            self.__dict__.setdefault('_host_ratio', []).append(self.host_enqueue_ms / max((perf_counter() - t_host0) * 1e3, 1e-3))
         self.d_loss, self.g_loss, self.h_loss = float(host[0]), float(host[1]), float(host[2])
         if apply_gradient_penalty:
             self.last_gp_loss = float(host[3])

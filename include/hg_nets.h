@@ -62,6 +62,13 @@ int hg_channel_sum(const float *g, float *out, int32_t B, int32_t C, int32_t HW,
 int hg_diffgrad_step(float *p, const float *g, float *exp_avg, float *exp_avg_sq, float *prev_grad,
                      int64_t n, float lr, float beta1, float beta2, float eps, int32_t step, void *stream);
 
+/* The same step with the bias-corrected step size lr*sqrt(1-b2^t)/(1-b1^t) read from device memory (one float):
+ * no per-step host value in the launch, so a captured hipGraph of the train step can replay it; the host writes
+ * hg_diffgrad_step_size(lr, b1, b2, t) there before each replay. */
+float hg_diffgrad_step_size(float lr, float beta1, float beta2, int32_t step);
+int hg_diffgrad_step_dev(float *p, const float *g, float *exp_avg, float *exp_avg_sq, float *prev_grad, int64_t n,
+                         const float *step_size_dev, float beta1, float beta2, float eps, void *stream);
+
 /* ma = beta*ma + (1-beta)*p over a flat buffer (HistoGAN.EMA). */
 int hg_ema_update(float *ma, const float *p, int64_t n, float beta, void *stream);
 

@@ -1,0 +1,48 @@
+"""hipGraph replay of the plain train step (histogan_amd/trainer.py::_graphed_step): the captured step must do exactly
+what the same static-input step does when run eagerly -- same kernels, same RNG stream, same parameters afterwards."""
+import random
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(mode, steps, tmp_path):
+    from histoGAN import Trainer
+    random.seed(3)
+    torch.manual_seed(3)
+    tr = Trainer(f'g{mode}', str(tmp_path / 'r'), str(tmp_path / 'm'), 32, 2, batch_size=2, hist_bin=16, hist_insz=32,
+                 hist_resizing='interpolation')
+    tr.graph_mode = mode
+    tr.run_evaluate = tr.run_save = False
+    tr.set_synthetic_data_src()
+    tr.init_GAN()
+    graphed = 0
+    for _ in range(steps):
+        tr.train(alpha=2)
+        graphed += int(tr.last_step_graphed)
+    torch.cuda.synchronize()
+    return tr, graphed
+
+
+def test_graph_replay_equals_static_eager_step(gpu_device, tmp_path):
+    a, ga = _run('2', 14, tmp_path)       # static inputs, no capture
+    b, gb = _run('1', 14, tmp_path)       # captured at step 6, replayed on every later plain step
+    assert ga == 0 and gb == 6 and not getattr(b, '_graph_failed', False)        # steps 6,7, 9,10,11, 13
+    for name in ('_flat_g', '_flat_d'):
+        assert torch.equal(getattr(a.GAN, name).data, getattr(b.GAN, name).data), name
+    assert a.GAN.G_opt.step_count == b.GAN.G_opt.step_count == 14
+    assert (a.d_loss, a.g_loss, a.h_loss) == (b.d_loss, b.g_loss, b.h_loss)
+    assert b.host_enqueue_ms < a.host_enqueue_ms
+
+
+def test_graph_auto_mode_decides_and_trains(gpu_device, tmp_path):
+    """'auto' measures the host share of the first eager plain steps; at this tiny size the step is host-bound, so the
+    graph is taken; losses stay finite; an eager gradient-penalty step in between sees the weights the replay left."""
+    tr, g = _run('auto', 16, tmp_path)
+    assert tr._graph_auto in (True, False)
+    import math
+    assert all(math.isfinite(v) for v in (tr.d_loss, tr.g_loss, tr.h_loss))
+    if tr._graph_auto:
+        assert g >= 5
