@@ -31,6 +31,7 @@ class HgHistParams(ctypes.Structure):
         ('intensity_scale', ctypes.c_int32),
         ('green_only', ctypes.c_int32),
         ('projection', ctypes.c_int32),
+        ('pre_relu', ctypes.c_int32),
     ]
 
 

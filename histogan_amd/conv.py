@@ -76,7 +76,7 @@ def _check_args(x, w, stride):
 # model and only change through DiffGrad.step / ema_update / load_state_dict -- the first two update through
 # raw pointers (no version counter moves) and therefore call `weights_changed()`.  Everything else (plain
 # torch users, the temporaries of a double backward) is packed on every call.
-_cacheable = {}      # (data_ptr, shape) of a registered weight -> owner (base address of the flat buffer it lives in)
+_cacheable = {}      # (data_ptr, shape) of a registered weight -> (owner = base address of its flat buffer, weakref to the parameter)
 _cache = {}
 _owner_gen = {}      # owner -> generation counter, bumped when that buffer's weights change
 
@@ -86,12 +86,36 @@ def _owner_of(t):
 
 
 def enable_pack_cache(params=None):
-    """Register convolution weights (4-D tensors among `params`) for packed-weight caching; None switches it off."""
-    _cache.clear()
-    _cacheable.clear()
-    for p in (params or ()):
+    """Register convolution weights (4-D tensors among `params`) for packed-weight caching; None switches caching off
+    and drops every registration.  Registration is ADDITIVE (a HistoGAN Trainer and a recoloring Trainer built side by
+    side -- the reference CLI does that -- both keep their entries) and holds only a weak reference to the parameter:
+    entries of a freed model are dropped on lookup, so a later tensor allocated at the same address cannot hit them."""
+    import weakref
+    if params is None:
+        _cache.clear()
+        _cacheable.clear()
+        return
+    for p in params:
         if p.dim() == 4:
-            _cacheable[(p.data_ptr(), tuple(p.shape))] = _owner_of(p)
+            key = (p.data_ptr(), tuple(p.shape))
+            for k in [k for k in _cache if k[0] == key]:
+                del _cache[k]
+            _cacheable[key] = (_owner_of(p), weakref.ref(p))
+
+
+def _registered_owner(w, key):
+    """Owner id of a registered, still-alive weight at `key`; None (and the stale entry dropped) otherwise."""
+    ent = _cacheable.get(key)
+    if ent is None:
+        return None
+    owner, ref = ent
+    p = ref()
+    if p is None or p.data_ptr() != key[0]:
+        del _cacheable[key]
+        for k in [k for k in _cache if k[0] == key]:
+            del _cache[k]
+        return None
+    return owner
 
 
 def weights_changed(flat=None):
@@ -114,7 +138,7 @@ def _stamp(w, owner):
 def cached(w, tag, compute):
     """compute(w) cached per registered weight and `tag` until that weight's buffer changes; uncached otherwise."""
     key = (w.data_ptr(), tuple(w.shape))
-    owner = _cacheable.get(key)
+    owner = _registered_owner(w, key)
     if owner is None:
         return compute(w)
     hit = _cache.get((key, tag))
@@ -129,7 +153,7 @@ def cached(w, tag, compute):
 def pack_weights(w, mode):
     """(Co,Ci,k,k) -> the packed operand Wt[k*k][Kp][Np] of hg_conv2d_fwd / hg_conv2d_dgrad."""
     key = (w.data_ptr(), tuple(w.shape))
-    owner = _cacheable.get(key)
+    owner = _registered_owner(w, key)
     if owner is not None:
         hit = _cache.get((key, mode))
         st = _stamp(w, owner)

@@ -56,6 +56,7 @@ struct DevParams {
   const int *rows, *cols;
   int h, P, method, intensity, green;
   int proj;                 // HG_PROJ_*: 0 RGB-uv (3 planes), 1 rg-chroma, 2 direct (Lab): one plane, run as `green`
+  int pre_relu;             // the caller's F.relu in front of the block (histoGAN.py:955) folded into the clamp mask
   int npix;
   double lo, hi, step;      // bins: i*step+lo, last == hi  (np.linspace)
   double inv_sigma_d;       // (double)(float)(1/sigma) -- pairs with inv_sigma
@@ -73,6 +74,13 @@ __device__ __forceinline__ double bin_center(const DevParams &P, int i) {
 }
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+// Gradient mask of the clamp (RGBuvHistBlock.py:76: passes where 0 <= x <= 1).  With pre_relu the F.relu the train
+// step applies first (histoGAN/histoGAN.py:955) is part of the block: clamp(relu(x)) == clamp(x) in the forward, and
+// the relu's mask (x > 0) only removes the point x == 0 from the clamp's.
+__device__ __forceinline__ bool grad_mask(const DevParams &P, float raw) {
+  return (P.pre_relu ? raw > 0.f : raw >= 0.f) && raw <= 1.f;
+}
 
 // Stage 0 (clamp + resize), RGBuvHistBlock.py:76-99.  n indexes the Hs x Ws sampled grid.
 __device__ __forceinline__ void sample_rgb(const DevParams &P, const float *xb, int n, float &r,
@@ -369,9 +377,9 @@ __device__ __forceinline__ void store_rgb_grad(const DevParams &P, const float *
     const long long xo = ys * P.sh + xs * P.sw;
     const float xr = xb[xo], xg = xb[xo + P.sc], xbv = xb[xo + 2 * P.sc];
     float *gb = gdst + ((long long)b * P.C) * P.npix + n;
-    gb[0] = (xr >= 0.f && xr <= 1.f) ? dr : 0.f;
-    gb[P.npix] = (xg >= 0.f && xg <= 1.f) ? dg : 0.f;
-    gb[2LL * P.npix] = (xbv >= 0.f && xbv <= 1.f) ? dbl : 0.f;
+    gb[0] = grad_mask(P, xr) ? dr : 0.f;
+    gb[P.npix] = grad_mask(P, xg) ? dg : 0.f;
+    gb[2LL * P.npix] = grad_mask(P, xbv) ? dbl : 0.f;
   } else {
     // gradient w.r.t. the resized (already clamped) image: gxs[b][3][Hs*Ws]
     float *gb = gdst + ((long long)b * 3) * P.npix + n;
@@ -1375,7 +1383,7 @@ __global__ __launch_bounds__(1024) void k_thr_bwd_lean(const DevParams P, const 
       pixel(clamp01(rc.z), clamp01(gc.z), clamp01(bc.z), or4.z, og4.z, ob4.z);
       pixel(clamp01(rc.w), clamp01(gc.w), clamp01(bc.w), or4.w, og4.w, ob4.w);
       // clamp mask of RGBuvHistBlock.py:76, decided on the raw value
-      auto m = [](float raw, float v) { return (raw >= 0.f && raw <= 1.f) ? v : 0.f; };
+      auto m = [&](float raw, float v) { return grad_mask(P, raw) ? v : 0.f; };
       or4 = make_float4(m(rc.x, or4.x), m(rc.y, or4.y), m(rc.z, or4.z), m(rc.w, or4.w));
       og4 = make_float4(m(gc.x, og4.x), m(gc.y, og4.y), m(gc.z, og4.z), m(gc.w, og4.w));
       ob4 = make_float4(m(bc.x, ob4.x), m(bc.y, ob4.y), m(bc.z, ob4.z), m(bc.w, ob4.w));
@@ -1593,7 +1601,7 @@ __global__ __launch_bounds__(256) void k_bilinear_adjoint(const DevParams P, con
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float xv = xb[c * P.sc];
-    dst[(long long)c * P.H * P.W] = (xv >= 0.f && xv <= 1.f) ? acc[c] : 0.f;
+    dst[(long long)c * P.H * P.W] = grad_mask(P, xv) ? acc[c] : 0.f;
   }
 }
 
@@ -1612,7 +1620,7 @@ __global__ __launch_bounds__(256) void k_sampling_adjoint(const DevParams P, con
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float xv = xb[c * P.sc];
-    if (xv >= 0.f && xv <= 1.f) atomicAdd(dst + (long long)c * P.H * P.W, gxs[((long long)b * 3 + c) * P.npix + n]);
+    if (grad_mask(P, xv)) atomicAdd(dst + (long long)c * P.H * P.W, gxs[((long long)b * 3 + c) * P.npix + n]);
   }
 }
 
@@ -1750,6 +1758,7 @@ DevParams make_dev(const hg_hist_params *p) {
   d.sb = p->stride_b; d.sc = p->stride_c; d.sh = p->stride_h; d.sw = p->stride_w;
   d.Hs = p->Hs; d.Ws = p->Ws; d.mode = p->resize_mode; d.rows = p->row_idx; d.cols = p->col_idx;
   d.proj = p->projection;
+  d.pre_relu = p->pre_relu ? 1 : 0;
   d.h = p->h; d.P = (p->green_only || p->projection) ? 1 : 3; d.method = p->method;
   d.intensity = p->intensity_scale ? 1 : 0; d.green = (p->green_only || p->projection) ? 1 : 0;
   d.npix = p->Hs * p->Ws;

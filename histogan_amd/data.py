@@ -23,7 +23,30 @@ import torch
 EXTS = ['jpg', 'png']
 
 
-def _load_rgb(path, size=None, flip=False, rgba=False):
+def _random_resized_crop_box(w, h, rs, scale=(0.5, 1.0), ratio=(0.98, 1.02)):
+    """torchvision.transforms.RandomResizedCrop.get_params restated (histoGAN/histoGAN.py:277-279 uses scale (0.5, 1),
+    ratio (0.98, 1.02)): up to 10 draws of (area fraction, log-uniform aspect), then the ratio-clamped centre crop."""
+    area = w * h
+    lr = np.log(ratio)
+    for _ in range(10):
+        target = area * rs.uniform(scale[0], scale[1])
+        ar = np.exp(rs.uniform(lr[0], lr[1]))
+        cw, ch = int(round(np.sqrt(target * ar))), int(round(np.sqrt(target / ar)))
+        if 0 < cw <= w and 0 < ch <= h:
+            return int(rs.randint(0, w - cw + 1)), int(rs.randint(0, h - ch + 1)), cw, ch
+    in_ratio = w / h
+    if in_ratio < ratio[0]:
+        cw, ch = w, int(round(w / ratio[0]))
+    elif in_ratio > ratio[1]:
+        cw, ch = int(round(h * ratio[1])), h
+    else:
+        cw, ch = w, h
+    return (w - cw) // 2, (h - ch) // 2, cw, ch
+
+
+def _load_rgb(path, size=None, flip=False, rgba=False, crop_seed=None):
+    """crop_seed: None = Resize + CenterCrop; an int = Resize + RandomResizedCrop(size, scale (0.5,1), ratio (0.98,1.02))
+    drawn from that seed (the `dataset_aug_prob` branch of the reference's transform, histoGAN/histoGAN.py:273-283)."""
     from PIL import Image
     img = Image.open(path).convert('RGBA' if rgba else 'RGB')    # convert_rgb_to_transparent / _transparent_to_rgb
     if size is not None:
@@ -31,8 +54,12 @@ def _load_rgb(path, size=None, flip=False, rgba=False):
         s = size / min(w, h)                                   # transforms.Resize(size): short side -> size
         img = img.resize((max(size, round(w * s)), max(size, round(h * s))), Image.BILINEAR)
         w, h = img.size
-        l, t = (w - size) // 2, (h - size) // 2                # transforms.CenterCrop(size)
-        img = img.crop((l, t, l + size, t + size))
+        if crop_seed is None:
+            l, t = (w - size) // 2, (h - size) // 2            # transforms.CenterCrop(size)
+            img = img.crop((l, t, l + size, t + size))
+        else:
+            l, t, cw, ch = _random_resized_crop_box(w, h, np.random.RandomState(crop_seed))
+            img = img.resize((size, size), Image.BILINEAR, box=(l, t, l + cw, t + ch))
     arr = np.asarray(img, dtype=np.float32) / 255.0            # ToTensor
     if flip:
         arr = arr[:, ::-1]                                     # transforms.RandomHorizontalFlip
@@ -41,7 +68,8 @@ def _load_rgb(path, size=None, flip=False, rgba=False):
 
 class FolderData:
     def __init__(self, folder, hist_block, batch_size, image_size, device, transparent=False, seed=0, test=False,
-                 hist_sampling=True, workers=8, prefetch=3, cache_hists=True, max_cached=200000, hflip=False):
+                 hist_sampling=True, workers=8, prefetch=3, cache_hists=True, max_cached=200000, hflip=False,
+                 aug_prob=0.0, max_cache_bytes=2 << 30):
         self.rgba = bool(transparent)                            # 4-channel items; the histogram uses channels 0..2
         self.paths = sorted(p for ext in EXTS for p in Path(f'{folder}').glob(f'**/*.{ext}'))
         if not self.paths:
@@ -52,8 +80,10 @@ class FolderData:
         # histogram (ReHistoGAN/rehistoGAN.py:375-446, `hist_sampling`)
         self.hist_sampling = hist_sampling
         self.hflip = hflip                                      # the reference's training transform flips with p = 0.5
+        self.aug_prob = float(aug_prob)                         # `dataset_aug_prob`: P(RandomResizedCrop instead of CenterCrop)
         self.cache = {} if cache_hists else None
         self.max_cached = max_cached
+        self.max_cache_bytes, self.cache_bytes = int(max_cache_bytes), 0   # device memory the cached histograms may take
         self.pool = ThreadPoolExecutor(max_workers=max(1, workers))
         self.queue = deque()
         self.prefetch = max(1, prefetch)
@@ -72,8 +102,10 @@ class FolderData:
         if self.cache is not None:
             need = {i for i in need if i not in self.cache}
         plan['full'] = {i: self.pool.submit(_load_rgb, self.paths[i], None, False, self.rgba) for i in sorted(need)}   # full resolution
-        plan['small'] = None if self.test else [self.pool.submit(_load_rgb, self.paths[int(i)], self.S, bool(f), self.rgba)
-                                                for i, f in zip(plan['img'], flips)]
+        crops = [int(self.rs.randint(0, 2 ** 31 - 1)) if (self.aug_prob > 0.0 and not self.test and self.rs.rand() < self.aug_prob)
+                 else None for _ in range(self.B)]
+        plan['small'] = None if self.test else [self.pool.submit(_load_rgb, self.paths[int(i)], self.S, bool(f), self.rgba, c)
+                                                for i, f, c in zip(plan['img'], flips, crops)]
         return plan
 
     def _hist(self, idx, plan):
@@ -87,8 +119,11 @@ class FolderData:
                 with torch.no_grad():
                     h = self.hist_block(x)[0]
                 self.misses += 1
-                if self.cache is not None and len(self.cache) < self.max_cached:
+                nbytes = h.numel() * h.element_size()
+                if self.cache is not None and len(self.cache) < self.max_cached and \
+                        self.cache_bytes + nbytes <= self.max_cache_bytes:
                     self.cache[i] = h
+                    self.cache_bytes += nbytes
             else:
                 self.hits += 1
             out.append(h)

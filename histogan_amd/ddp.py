@@ -32,6 +32,14 @@ def broadcast_flat(flat, src=0):
         dist.broadcast(flat.data, src)
 
 
+def broadcast_buffers(module, src=0):
+    """Module buffers (the VectorQuantize codebooks of `fq_layers`) are drawn per rank at construction: replicas start
+    from rank `src`'s copy, like the parameters."""
+    if is_dist():
+        for b in module.buffers():
+            dist.broadcast(b.data, src)
+
+
 class GradAllReduce:
     """Averaging all-reduce of a flat gradient buffer, optionally asynchronous."""
 

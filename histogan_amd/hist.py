@@ -45,7 +45,7 @@ class HistConfig:
         self.lo, self.hi = float(hb[0]), float(hb[1])
 
 
-def _make_params(x, cfg):
+def _make_params(x, cfg, pre_relu=False):
     if x.dim() != 4 or x.shape[1] < 3:
         raise ValueError(f'expected (B, C>=3, H, W) input, got {tuple(x.shape)}')
     if cfg.method not in _lib.HG_METHOD:
@@ -74,6 +74,7 @@ def _make_params(x, cfg):
     p.sigma = float(cfg.sigma) if cfg.method != 'thresholding' else 1.0
     p.intensity_scale, p.green_only = int(cfg.intensity_scale), int(cfg.green_only)
     p.projection = _lib.HG_PROJ[cfg.projection]
+    p.pre_relu = int(bool(pre_relu))
     return p, keep
 
 
@@ -95,12 +96,13 @@ def _require_gpu(x, what):
 
 class RGBuvHistFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, cfg):
+    def forward(ctx, x, cfg, pre_relu=False):
         _require_gpu(x, 'RGBuvHistFunction')
         x = x.detach()
         if x.dtype != torch.float32:
             x = x.float()
-        p, keep = _make_params(x, cfg)
+        p, keep = _make_params(x, cfg, pre_relu)
+        ctx.pre_relu = pre_relu
         fwd_b, _ = _ws_bytes(p)
         with torch.cuda.device(x.device):
             P = 1 if (cfg.green_only or cfg.projection != 'rgbuv') else 3
@@ -118,7 +120,7 @@ class RGBuvHistFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         x, out, sums = ctx.saved_tensors
         cfg = ctx.cfg
-        p, keep = _make_params(x, cfg)
+        p, keep = _make_params(x, cfg, ctx.pre_relu)
         _, bwd_b = _ws_bytes(p)
         g = grad_out.detach()
         if g.dtype != torch.float32:
@@ -130,12 +132,48 @@ class RGBuvHistFunction(torch.autograd.Function):
             check(lib.hg_rgbuv_hist_bwd(ctypes.byref(p), x.data_ptr(), g.data_ptr(), out.data_ptr(),
                                         sums.data_ptr(), gx.data_ptr(), ws.data_ptr(), ws.numel(),
                                         _stream(x.device)), 'hg_rgbuv_hist_bwd')
-        return gx, None
+        return gx, None, None
 
 
-def rgbuv_hist(x, cfg):
-    """Differentiable RGB-uv histogram of x (B,C>=3,H,W) -> (B, 3|1, h, h), on x's GPU."""
-    return RGBuvHistFunction.apply(x, cfg)
+_CPU_REDIRECT_WARNED = False
+
+
+def run_block(x, cfg, device, what, pre_relu=False):
+    """forward() of the drop-in histogram modules: resolves the module's `device` argument the way the reference does
+    ('cuda', 'cpu', an ordinal, a torch.device).
+
+    device='cpu' is what the reference's Dataset uses inside DataLoader workers (histoGAN/histoGAN.py:263-266, 296-302).
+    This build has no CPU kernels: such a call is REDIRECTED -- computed on the current GPU, result returned on the CPU
+    (the reference contract: output lives on `device`), with one warning.  Inside a forked DataLoader worker the GPU
+    must not be touched at all (HIP state does not survive fork): there the call raises with a pointer to the
+    restructured data source (histogan_amd/data.FolderData computes and caches the target histograms on the GPU)."""
+    global _CPU_REDIRECT_WARNED
+    dev = torch.device('cuda', device) if isinstance(device, int) else torch.device(device)
+    to_cpu = dev.type != 'cuda'
+    if to_cpu:
+        import torch.utils.data as tud
+        if tud.get_worker_info() is not None:
+            raise RuntimeError(f"{what}(device={device!r}) inside a DataLoader worker: the MI355X-native build has no CPU "
+                               "kernels and a forked worker must not touch the GPU; use histogan_amd.data.FolderData "
+                               "(Trainer.set_data_src), which computes the target histograms on the GPU and caches them")
+        if not torch.cuda.is_available():
+            raise RuntimeError(f"{what}(device={device!r}): the MI355X-native build has no CPU path and no GPU is visible")
+        if not _CPU_REDIRECT_WARNED:
+            import warnings
+            warnings.warn(f"{what}(device={device!r}): no CPU kernels in the MI355X-native build; computing on "
+                          f"cuda:{torch.cuda.current_device()} and returning the histogram on the CPU")
+            _CPU_REDIRECT_WARNED = True
+        dev = torch.device('cuda', torch.cuda.current_device())
+    if not x.is_cuda:
+        x = x.to(dev)
+    out = rgbuv_hist(x, cfg, pre_relu)
+    return out.cpu() if to_cpu else out
+
+
+def rgbuv_hist(x, cfg, pre_relu=False):
+    """Differentiable RGB-uv histogram of x (B,C>=3,H,W) -> (B, 3|1, h, h), on x's GPU.  pre_relu: the result and
+    gradient of `rgbuv_hist(F.relu(x))` (the train step's call, histoGAN/histoGAN.py:955) without the relu launch."""
+    return RGBuvHistFunction.apply(x, cfg, pre_relu)
 
 
 class HellingerFunction(torch.autograd.Function):

@@ -330,8 +330,9 @@ class VectorQuantize(nn.Module):
     from the third-party `vector_quantize_pytorch`, absent from the reference tree and unpinned: restated from the
     published algorithm -- VQ-VAE codebook with exponential-moving-average updates, straight-through estimator and
     commitment loss -- PARITY UNPINNED).  Buffers `embed` (dim, n_embed), `cluster_size`, `embed_avg` as upstream.
-    Nearest-code search and the EMA statistics are two small GEMMs (rocBLAS); under data parallelism every rank
-    updates its own codebook from its own shard (the reference is single-GPU)."""
+    Nearest-code search and the EMA statistics are two small GEMMs (rocBLAS); under data parallelism the statistics are
+    all-reduced (counts and sums of the global batch) and the buffers broadcast at init / after load, so every replica
+    holds the same codebook (the reference is single-GPU)."""
 
     def __init__(self, dim, n_embed, decay=0.8, commitment=1., eps=1e-5):
         super().__init__()
@@ -349,8 +350,14 @@ class VectorQuantize(nn.Module):
         if self.training:
             with torch.no_grad():
                 onehot = F.one_hot(embed_ind, self.n_embed).type(input.dtype)
-                self.cluster_size.mul_(self.decay).add_(onehot.sum(0), alpha=1 - self.decay)
-                self.embed_avg.mul_(self.decay).add_(flatten.detach().transpose(0, 1) @ onehot, alpha=1 - self.decay)
+                counts, sums = onehot.sum(0), flatten.detach().transpose(0, 1) @ onehot
+                from . import ddp
+                if ddp.is_dist():            # the codebook statistics of the GLOBAL batch: replicas keep identical codebooks
+                    packed = torch.cat([counts.reshape(1, -1), sums], dim=0)
+                    torch.distributed.all_reduce(packed)
+                    counts, sums = packed[0], packed[1:]
+                self.cluster_size.mul_(self.decay).add_(counts, alpha=1 - self.decay)
+                self.embed_avg.mul_(self.decay).add_(sums, alpha=1 - self.decay)
                 n = self.cluster_size.sum()
                 cluster_size = (self.cluster_size + self.eps) / (n + self.n_embed * self.eps) * n     # Laplace smoothing
                 self.embed.copy_(self.embed_avg / cluster_size.unsqueeze(0))

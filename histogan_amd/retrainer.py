@@ -254,7 +254,8 @@ class recoloringTrainer():
     def set_data_src(self, folder, sampling=True):
         from .data import FolderData
         self.loader = FolderData(folder, self.histBlock, self.batch_size, self.image_size, self.device,
-                                 transparent=self.transparent, seed=ddp.rank(), hist_sampling=sampling)
+                                 transparent=self.transparent, seed=ddp.rank(), hist_sampling=sampling,
+                                 hflip=True)     # transforms.RandomHorizontalFlip(), ReHistoGAN/rehistoGAN.py:362
         self.loader_evaluate = FolderData(folder, self.histBlock, 4, self.image_size, self.device,
                                           transparent=self.transparent, seed=977 + ddp.rank(),
                                           hist_sampling=sampling)
@@ -373,7 +374,7 @@ class recoloringTrainer():
                 d_updated = True
             fake_output, _ = Disc(generated_images)
             d_loss = gamma * fake_output.mean()
-            generated_histograms = self.histBlock(F.relu(generated_images))
+            generated_histograms = self.histBlock(generated_images, pre_relu=True)   # == histBlock(F.relu(.)), reference :955
             histogram_loss = hellinger_loss(hist_batch, generated_histograms, alpha)
             rec_loss = beta * self.rec_loss_func.compute_loss(image_batch, generated_images)
             gen_loss = d_loss + histogram_loss + rec_loss
@@ -487,9 +488,10 @@ class recoloringTrainer():
             file_paths = [p for p in Path(self.models_dir / self.name).glob('model_*.pt')]
             saved_nums = sorted(map(lambda x: int(x.stem.split('_')[1]), file_paths))
             if len(saved_nums) == 0:
-                return
+                return -1          # reference ReHistoGAN/rehistoGAN.py:1218: the CLI copies the pretrained HistoGAN head only then
             name = saved_nums[-1]
             print(f'continuing from previous epoch - {name}')
         self.steps = name * self.save_every
         self.GAN.load_state_dict(torch.load(self.model_name(name), map_location=self.device))
         weights_changed()
+        return 0

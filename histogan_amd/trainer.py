@@ -189,6 +189,7 @@ class HistoGAN(nn.Module):
         # replicas start identical under data parallelism
         for f in (self._flat_g, self._flat_d, self._flat_ema):
             ddp.broadcast_flat(f)
+        ddp.broadcast_buffers(self)
         self._reduce_g = ddp.GradAllReduce(self._flat_g)
         self._reduce_d = ddp.GradAllReduce(self._flat_d)
         # packed conv weights are reused between the forward passes of one step (invalidated by the optimizers)
@@ -335,7 +336,7 @@ class Trainer():
     def set_data_src(self, folder):
         from .data import FolderData
         self.loader = FolderData(folder, self.histBlock, self.batch_size, self.image_size, self.device,
-                                 transparent=self.transparent, seed=ddp.rank())
+                                 transparent=self.transparent, seed=ddp.rank(), aug_prob=self.dataset_aug_prob)
         self.loader_evaluate = FolderData(folder, self.histBlock, 4, self.image_size, self.device,
                                           transparent=self.transparent, seed=977 + ddp.rank(), test=True)
 
@@ -575,7 +576,7 @@ class Trainer():
                 GAN.D_opt.step()
                 d_updated = True
             fake_output, _ = Disc(aug(generated_images))
-            generated_histograms = self.histBlock(F.relu(generated_images))
+            generated_histograms = self.histBlock(generated_images, pre_relu=True)   # == histBlock(F.relu(.)), reference :955
             histogram_loss = hellinger_loss(hist_batch, generated_histograms, alpha)
             loss = fake_output.mean()
             gen_loss = loss + histogram_loss
@@ -587,8 +588,10 @@ class Trainer():
                 pl_len = pl_lengths.detach().mean()
                 if not is_empty(self.pl_mean):
                     pl_loss = ((pl_lengths - self.pl_mean) ** 2).mean()
-                    # reference: added only if not NaN (:974) -- nan_to_num keeps that without a host sync
-                    gen_loss = gen_loss + torch.where(torch.isnan(pl_loss), torch.zeros_like(pl_loss), pl_loss)
+                    # reference :974: added only if not NaN.  A masked value would still send 0 * NaN gradients back through
+                    # the second generator pass, so this is a real branch -- one host sync on every 32nd step.
+                    if not bool(torch.isnan(pl_loss)):
+                        gen_loss = gen_loss + pl_loss
             gen_loss = gen_loss / acc
             gen_loss.backward()
             total_gen_loss += loss.detach() / acc
@@ -623,16 +626,16 @@ class Trainer():
         self.last_step_graphed = getattr(self, '_graph', None) is not None and not (apply_gradient_penalty or apply_path_penalty)
         self._t_host0 = t_host0
         if ddp.is_dist():
-            nan_flag = torch.isnan(stats[:2]).any().double().reshape(1)
+            nan_flag = torch.isnan(stats[:4]).any().double().reshape(1)
             packed = torch.cat([stats, nan_flag])
             torch.distributed.all_reduce(packed[:6], op=torch.distributed.ReduceOp.SUM)
             torch.distributed.all_reduce(packed[6:], op=torch.distributed.ReduceOp.MAX)
             packed[:6] /= ddp.world_size()
             host = packed.cpu().numpy()
-            has_nan = host[6] > 0 or np.isnan(host[:2]).any()
+            has_nan = host[6] > 0 or np.isnan(host[:2]).any() or np.isnan(host[3])
         else:
             host = stats.cpu().numpy()
-            has_nan = bool(np.isnan(host[:2]).any())
+            has_nan = bool(np.isnan(host[:2]).any() or np.isnan(host[3]))     # incl. the gradient penalty (reference's raise_if_nan on disc_loss)
         if self.graph_mode == 'auto' and getattr(self, '_graph_auto', None) is None and self.steps >= 2 \
                 and not (apply_gradient_penalty or apply_path_penalty):
             # eager plain step: share of its wall time (up to the read-back's return) the host spent enqueueing
@@ -762,4 +765,5 @@ class Trainer():
             print(f'continuing from previous epoch - {name}')
         self.steps = name * self.save_every
         self.GAN.load_state_dict(torch.load(self.model_name(name), map_location=self.device))
+        ddp.broadcast_buffers(self.GAN)
         weights_changed()

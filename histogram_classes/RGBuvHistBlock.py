@@ -7,7 +7,7 @@ gfx950 kernels of histogan_amd/csrc/hg_hist.hip through the C ABI of include/hg_
 import torch
 import torch.nn as nn
 
-from histogan_amd.hist import HistConfig, rgbuv_hist
+from histogan_amd.hist import HistConfig, run_block
 
 EPS = 1e-6
 
@@ -23,7 +23,7 @@ class RGBuvHistBlock(nn.Module):
     strided samples); method in {'thresholding', 'RBF', 'inverse-quadratic'}; sigma of the
     RBF / inverse-quadratic kernel; intensity_scale (I_y weighting); hist_boundary (default
     [-3, 3], sorted in place like the reference); green_only (only the log(g/r), log(g/b) plane).
-    `device` must be a GPU: this build has no CPU path.
+    `device`: a GPU; 'cpu' is redirected to the current GPU with the result returned on the CPU (histogan_amd.hist.run_block).
     """
     super(RGBuvHistBlock, self).__init__()
     self.h = h
@@ -47,11 +47,8 @@ class RGBuvHistBlock(nn.Module):
                       sigma=getattr(self, 'sigma', 0.02), intensity_scale=self.intensity_scale,
                       hist_boundary=list(self.hist_boundary), green_only=self.green_only)
 
-  def forward(self, x):
-    """x: float (B, C>=3, H, W) on the GPU -> float32 (B, 3 or 1, h, h), L1-normalised per image."""
-    dev = torch.device('cuda', self.device) if isinstance(self.device, int) else torch.device(self.device)
-    if dev.type != 'cuda':
-      raise RuntimeError("RGBuvHistBlock(device=%r): the MI355X-native build has no CPU path" % (self.device,))
-    if not x.is_cuda:
-      x = x.to(dev)
-    return rgbuv_hist(x, self._config())
+  def forward(self, x, pre_relu=False):
+    """x: float (B, C>=3, H, W) -> float32 (B, 3 or 1, h, h), L1-normalised per image, on `device`.
+    pre_relu=True: the value and gradient of forward(F.relu(x)) -- the train step's call (histoGAN/histoGAN.py:955) --
+    with the relu folded into the kernel's clamp mask (an extension; the reference signature is forward(x))."""
+    return run_block(x, self._config(), self.device, 'RGBuvHistBlock', pre_relu)

@@ -5,7 +5,7 @@ include/hg_hist.h: one plane, shared clamp / resize / soft-binning / normalisati
 import torch
 import torch.nn as nn
 
-from histogan_amd.hist import HistConfig, rgbuv_hist
+from histogan_amd.hist import HistConfig, run_block
 
 EPS = 1e-6
 
@@ -34,13 +34,8 @@ class rgChromaHistBlock(nn.Module):
       self.sigma = sigma
 
   def forward(self, x):
-    """x: float (B, C>=3, H, W) on the GPU -> float32 (B, 1, h, h), L1-normalised per image."""
-    dev = torch.device('cuda', self.device) if isinstance(self.device, int) else torch.device(self.device)
-    if dev.type != 'cuda':
-      raise RuntimeError("rgChromaHistBlock(device=%r): the MI355X-native build has no CPU path" % (self.device,))
-    if not x.is_cuda:
-      x = x.to(dev)
+    """x: float (B, C>=3, H, W) -> float32 (B, 1, h, h), L1-normalised per image, on `device`."""
     cfg = HistConfig(h=self.h, insz=self.insz, resizing=self.resizing, method=self.method,
                      sigma=getattr(self, 'sigma', 0.02), intensity_scale=self.intensity_scale,
                      hist_boundary=list(self.hist_boundary), projection='rgchroma')
-    return rgbuv_hist(x, cfg)
+    return run_block(x, cfg, self.device, 'rgChromaHistBlock')

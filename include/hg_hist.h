@@ -64,6 +64,9 @@ typedef struct hg_hist_params {
    * 1: rg-chroma (u,v) = (R,G)/(R+G+B+1e-6), weight Iy   (histogram_classes/rgChromaHistBlock.py:100-141)
    * 2: direct     (u,v) = channels (1,2), weight = channel 0  (histogram_classes/LabHistBlock.py:102-140) */
   int32_t projection;
+  /* 1: the F.relu the train step puts in front of the block (histoGAN/histoGAN.py:955) is part of the call -- identical
+   * forward (clamp(relu(x)) == clamp(x)); the backward masks x <= 0 instead of x < 0.  Saves that aten launch and node. */
+  int32_t pre_relu;
 } hg_hist_params;
 
 /* library / build identification */

@@ -75,3 +75,31 @@ def test_cpu_tensor_is_refused_loudly(L):
     from histogram_classes.RGBuvHistBlock import RGBuvHistBlock
     with pytest.raises(RuntimeError):
         RGBuvHistBlock(device='cpu')(torch.rand(1, 3, 8, 8))
+
+
+def test_pack_cache_registration_is_additive_and_weak():
+    """a second model's enable_pack_cache() must not drop the first one's entries, and entries of a freed
+    model must not be hit by a later tensor (host logic only, no kernels)."""
+    import gc
+    import torch
+    from histogan_amd import conv as C
+    C.enable_pack_cache(None)
+    a = [torch.nn.Parameter(torch.zeros(4, 3, 3, 3)), torch.nn.Parameter(torch.zeros(5))]
+    b = [torch.nn.Parameter(torch.zeros(2, 2, 1, 1))]
+    C.enable_pack_cache(a)
+    C.enable_pack_cache(b)
+    ka, kb = (a[0].data_ptr(), (4, 3, 3, 3)), (b[0].data_ptr(), (2, 2, 1, 1))
+    assert C._registered_owner(a[0], ka) is not None and C._registered_owner(b[0], kb) is not None
+    assert len(C._cacheable) == 2                       # the 1-D parameter is not a convolution weight
+    calls = []
+    v1 = C.cached(a[0], 'tag', lambda t: calls.append(1) or 'x')
+    v2 = C.cached(a[0], 'tag', lambda t: calls.append(1) or 'y')
+    assert (v1, v2, len(calls)) == ('x', 'x', 1)        # cached
+    C.weights_changed(a[0].data)
+    assert C.cached(a[0], 'tag', lambda t: 'z') == 'z'  # invalidated through its owner buffer
+    del a
+    gc.collect()
+    fake = torch.zeros(4, 3, 3, 3)
+    assert C._registered_owner(fake, ka) is None and ka not in C._cacheable     # dead owner: dropped on lookup
+    C.enable_pack_cache(None)
+    assert not C._cacheable

@@ -79,3 +79,35 @@ def test_resize_crop_flip_and_grid(folder, tmp_path):
     save_image_grid(torch.rand(5, 3, 8, 8), out, nrow=4)
     from PIL import Image
     assert Image.open(out).size == (4 * 10 + 2, 2 * 10 + 2)
+
+
+def test_dataset_aug_prob_random_resized_crop(folder):
+    """`dataset_aug_prob` (reference histoGAN/histoGAN.py:273-283): RandomResizedCrop(scale (0.5,1), ratio (0.98,1.02))
+    with that probability, CenterCrop otherwise; deterministic for a seed; the crop box obeys the scale / ratio ranges."""
+    from histogan_amd.data import _random_resized_crop_box
+    rs = np.random.RandomState(1)
+    for _ in range(200):
+        w, h = int(rs.randint(16, 300)), int(rs.randint(16, 300))
+        l, t, cw, ch = _random_resized_crop_box(w, h, rs)
+        assert 0 <= l and 0 <= t and l + cw <= w and t + ch <= h and cw > 0 and ch > 0
+    # on a square image the draw always fits: area in [0.5, 1] of the image, aspect in [0.98, 1.02] (up to rounding)
+    for _ in range(100):
+        l, t, cw, ch = _random_resized_crop_box(256, 256, rs)
+        assert 0.49 <= cw * ch / 65536 <= 1.0 and 0.96 <= cw / ch <= 1.04
+    dev = torch.device('cpu')
+    a = FolderData(folder, FakeHist(), 4, 16, dev, seed=5, aug_prob=1.0, workers=2)
+    b = FolderData(folder, FakeHist(), 4, 16, dev, seed=5, aug_prob=1.0, workers=2)
+    c = FolderData(folder, FakeHist(), 4, 16, dev, seed=5, aug_prob=0.0, workers=2)
+    xa, xb, xc = next(a)['images'], next(b)['images'], next(c)['images']
+    assert xa.shape == (4, 3, 16, 16) and torch.equal(xa, xb)
+    assert not torch.equal(xa, xc)                     # the crop changed what the batch shows
+    assert float(xa.min()) >= 0.0 and float(xa.max()) <= 1.0
+
+
+def test_histogram_cache_is_bounded_in_bytes(folder):
+    dev = torch.device('cpu')
+    one = 3 * 4 * 4 * 4                                 # bytes of one FakeHist histogram
+    src = FolderData(folder, FakeHist(), 4, 16, dev, seed=0, workers=2, max_cache_bytes=3 * one)
+    for _ in range(6):
+        next(src)
+    assert len(src.cache) == 3 and src.cache_bytes == 3 * one

@@ -126,8 +126,9 @@ def test_module_surface_matches_reference_contract(gpu_device):
     with pytest.raises(Exception, match='Wrong resizing method'):
         RGBuvHistBlock(h=16, insz=8, resizing='nearest')(x.to(gpu_device))
     RGBuvHistBlock(h=16, insz=64, resizing='nearest')(x.to(gpu_device))    # not reached when no resize is needed (:80-93)
-    with pytest.raises(RuntimeError):
-        RGBuvHistBlock(h=16, device='cpu')(x)
+    with pytest.warns(UserWarning, match='no CPU kernels'):                  # device='cpu': computed on the GPU, returned on the CPU
+        out_cpu = RGBuvHistBlock(h=16, device='cpu')(x)
+    assert out_cpu.device.type == 'cpu' and relmax(out_cpu.numpy(), ref) <= FWD_TOL
     # sums to one over all planes; one plane when green_only
     s = RGBuvHistBlock(h=16)(x.to(gpu_device)).sum(dim=(1, 2, 3))
     assert torch.allclose(s, torch.ones_like(s), atol=1e-5)
@@ -263,3 +264,30 @@ def test_fast_window_classification_is_exact(gpu_device, monkeypatch):
             res.append((out.detach().clone(), xg.grad.clone()))
         assert torch.equal(res[0][0], res[1][0])
         assert torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize('kw', [dict(h=32, insz=64), dict(h=16, insz=24, resizing='interpolation'),
+                                dict(h=16, insz=64, resizing='sampling'), dict(h=32, insz=64, method='thresholding'),
+                                dict(h=16, insz=64, hist_boundary=[-2.0, 3.0])])
+def test_pre_relu_equals_relu_in_front(kw, gpu_device):
+    """forward(x, pre_relu=True) == forward(F.relu(x)) in value and gradient (the train step's call, histoGAN.py:955):
+    generator-like input with negative values, exact zeros (the one point where relu's mask differs from clamp's)
+    and values above 1."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    x = 0.5 + 0.7 * torch.randn(2, 3, 40, 48, generator=g)
+    x[0, :, :6] = 0.0
+    x[1, 1, 10:20] = 0.0
+    blk = _block(kw)
+    go = None
+    res = []
+    for fused in (False, True):
+        xg = x.to(gpu_device).requires_grad_(True)
+        out = blk(xg, pre_relu=True) if fused else blk(F.relu(xg))
+        if go is None:
+            go = (torch.rand(out.shape, generator=g) - 0.3).to(gpu_device)
+        out.backward(go)
+        res.append((out.detach(), xg.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    assert float(res[1][1][0, :, :6].abs().max()) == 0.0           # relu's mask at x == 0

@@ -428,3 +428,49 @@ def test_vector_quantize_layers(gpu_device, tmp_path):
     tr.set_synthetic_data_src()
     tr.train(alpha=2); tr.train(alpha=2)
     assert np.isfinite(tr.d_loss) and np.isfinite(tr.g_loss) and tr.q_loss > 0
+
+
+@pytest.mark.parametrize('up', [True, False])
+def test_generator_block_forward_explicit_noise(up, gpu_device):
+    """GeneratorBlock.forward_ with explicit per-pixel noise tensors (the projection scripts' call, reference
+    histoGAN/histoGAN.py:481-502) vs. the inoise path and vs. the reference formula written with aten ops:
+    noise_k = to_noise_k(inoise[:, :H, :W]).permute(0, 3, 2, 1) (the H<->W swap of :465-466)."""
+    from histogan_amd.nets import GeneratorBlock
+    torch.manual_seed(4)
+    B, Ci, Co, H = 2, 12, 8, 16
+    blk = GeneratorBlock(32, Ci, Co, upsample=up, upsample_rgb=True).to(gpu_device)
+    with torch.no_grad():
+        blk.to_noise1.weight.normal_(std=0.5); blk.to_noise2.weight.normal_(std=0.5)
+        blk.to_noise1.bias.normal_(std=0.1); blk.to_noise2.bias.normal_(std=0.1)
+    Hin = H // 2 if up else H
+    x = torch.randn(B, Ci, Hin, Hin, device=gpu_device, requires_grad=True)
+    prev = torch.randn(B, 3, H, H, device=gpu_device)
+    istyle = torch.randn(B, 32, device=gpu_device)
+    inoise = torch.rand(B, 32, 32, 1, device=gpu_device)
+    s1, s2, srgb = blk.to_style1(istyle), blk.to_style2(istyle), blk.to_rgb.to_style(istyle)
+    cut = inoise[:, :H, :H, :]
+    n1 = blk.to_noise1(cut).permute(0, 3, 2, 1)
+    n2 = blk.to_noise2(cut).permute(0, 3, 2, 1)
+    xa, rgba = blk.forward_(x, prev, s1, s2, srgb, noise1=n1, noise2=n2)
+    xb, rgbb = blk.forward_(x, prev, s1, s2, srgb, inoise=inoise)
+    assert relmax(xa.detach().cpu().numpy(), xb.detach().cpu().numpy()) <= 2e-6
+    assert relmax(rgba.detach().cpu().numpy(), rgbb.detach().cpu().numpy()) <= 2e-6
+    (ga,) = torch.autograd.grad((xa * xa).sum() + rgba.sum(), x, retain_graph=True)
+    (gb,) = torch.autograd.grad((xb * xb).sum() + rgbb.sum(), x)
+    assert relmax(ga.cpu().numpy(), gb.cpu().numpy()) <= 2e-5
+    # the reference formula for one stage with aten ops in fp64 (Conv2DMod :420-440 on materialised per-sample weights)
+    with torch.no_grad():
+        xd = x.detach().double()
+        if up:
+            xd = F.interpolate(xd, scale_factor=2, mode='bilinear', align_corners=False)
+        w = blk.conv1.weight.double()[None] * (s1.double()[:, None, :, None, None] + 1)
+        w = w * torch.rsqrt((w ** 2).sum(dim=(2, 3, 4), keepdim=True) + 1e-8)
+        ref = torch.cat([F.conv2d(xd[b:b + 1], w[b], padding=1) for b in range(B)])
+        ref = F.leaky_relu(ref + n1.double(), 0.2)
+        w2 = blk.conv2.weight.double()[None] * (s2.double()[:, None, :, None, None] + 1)
+        w2 = w2 * torch.rsqrt((w2 ** 2).sum(dim=(2, 3, 4), keepdim=True) + 1e-8)
+        ref = torch.cat([F.conv2d(ref[b:b + 1], w2[b], padding=1) for b in range(B)])
+        ref = F.leaky_relu(ref + n2.double(), 0.2)
+    assert relmax(xa.detach().cpu().numpy(), ref.cpu().numpy()) <= 1e-5
+    with pytest.raises(Exception, match='No noise is given'):
+        blk.forward_(x, prev, s1, s2, srgb)

@@ -253,3 +253,13 @@ def test_train_step_matches_oracle(skip, internal, rec, gpu_device, tmp_path):
         # near the clamp edge); the Sobel magnitude adds sqrt() near zero
         assert e <= 1e-2, (p, k, e)
     print('worst generator-side gradient error', worst)
+
+
+def test_load_return_contract(gpu_device, tmp_path):
+    """recoloringTrainer.load(): -1 when no checkpoint exists, 0 after loading one (ReHistoGAN/rehistoGAN.py:1210-1226);
+    the reference CLI copies the pretrained HistoGAN head only on -1."""
+    from ReHistoGAN import recoloringTrainer
+    tr = recoloringTrainer('ld', str(tmp_path / 'r'), str(tmp_path / 'm'), 64, 2, batch_size=2, hist_bin=16, hist_insz=32)
+    assert tr.load(-1) == -1
+    tr.save(0)
+    assert tr.load(-1) == 0 and tr.load(0) == 0
