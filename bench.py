@@ -109,6 +109,45 @@ def recorded_traffic(key):
         return None
 
 
+def thr_probe_batch(dev, B, S, h, iters=10):
+    """Forward + backward of the thresholding histogram through the C ABI at another batch size (HIP events)."""
+    import ctypes
+    from histogan_amd import hist as HH
+    from histogan_amd._lib import lib, check
+    x = torch.rand(B, 3, S, S, device=dev)
+    p, keep = HH._make_params(x, HH.HistConfig(h=h, insz=S, method='thresholding'))
+    fb, bb = HH._ws_bytes(p)
+    out = torch.empty(B, 3, h, h, device=dev); sums = torch.empty(B, device=dev); gx = torch.empty_like(x)
+    gout = torch.rand(B, 3, h, h, device=dev) - 0.5
+    ws = torch.empty(max(fb, bb, 4), dtype=torch.uint8, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
+    for it in range(iters + 2):
+        e = evs[max(it - 2, 0)]
+        e[0].record()
+        check(lib.hg_rgbuv_hist_fwd(ctypes.byref(p), x.data_ptr(), out.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws.numel(), st), 'fwd')
+        e[1].record()
+        check(lib.hg_rgbuv_hist_bwd(ctypes.byref(p), x.data_ptr(), gout.data_ptr(), out.data_ptr(), sums.data_ptr(), gx.data_ptr(), ws.data_ptr(), ws.numel(), st), 'bwd')
+        e[2].record()
+    torch.cuda.synchronize()
+    tf = sum(e[0].elapsed_time(e[1]) for e in evs) / iters * 1e-3
+    tb = sum(e[1].elapsed_time(e[2]) for e in evs) / iters * 1e-3
+    nbytes = B * (3 * S * S + 3 * h * h) * 4 + B * (6 * S * S + 3 * h * h) * 4
+    del x, gx, ws
+    torch.cuda.empty_cache()
+    return {'fwd_ms': tf * 1e3, 'bwd_ms': tb * 1e3, 'achieved': nbytes / (tf + tb) / 1e9, 'unit': 'GB/s',
+            'frac': nbytes / (tf + tb) / 1e9 / HBM_PEAK_GBPS, 'bytes': nbytes}
+
+
+def recorded_value(key):
+    """A number taken from a committed rocprofv3 run (profiles/r02_recorded.json), None if not recorded."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r02_recorded.json')) as f:
+            return json.load(f)[key]
+    except Exception:
+        return None
+
+
 def conv_kernel_times(dev, B, iters=6):
     """HIP events (torch's current stream == the stream the C ABI launches on) around hg_conv2d_fwd /
     hg_conv2d_dgrad / hg_conv2d_wgrad with preallocated buffers, for every generator 3x3 layer.
@@ -149,29 +188,29 @@ def conv_kernel_times(dev, B, iters=6):
     return out
 
 
-def cpu_baseline_train(args):
-    """The oracle (CPU restatement of the reference networks + histogram block) doing the compute of one train
-    step -- D phase: G fwd (no grad), D on fake and real, backward; G phase: G fwd, D fwd, RGB-uv histogram +
-    Hellinger loss, backward; DiffGrad over all parameters -- on a bounded sample of the batch."""
+def oracle_train_step(args, n, device):
+    """The reference's op chain for one train step (oracle/: functional restatement of its networks + histogram block,
+    stock aten ops) on `device`, for n images -- D phase: G fwd (no grad), D on fake and real, backward; G phase: G fwd,
+    D fwd, RGB-uv histogram + Hellinger loss, backward.  Returns (one_step, diffgrad_once, n_params)."""
     import torch.nn.functional as F
     from histogan_amd.nets import Discriminator, Generator, HistVectorizer, StyleVectorizer
     from oracle import histogan_nets as N
     from oracle import rgbuv_hist as O
-    S, cap, h, n = args.size, args.capacity, args.bins, args.cpu_images
+    S, cap, h = args.size, args.capacity, args.bins
     L = int(__import__('math').log2(S)) - 1
     torch.manual_seed(0)
-    sd = {k: {kk: v.detach().requires_grad_(True) for kk, v in m.state_dict(keep_vars=True).items()}
+    sd = {k: {kk: v.detach().to(device).requires_grad_(True) for kk, v in m.state_dict(keep_vars=True).items()}
           for k, m in dict(G=Generator(S, 512, cap), D=Discriminator(S, cap), S=StyleVectorizer(512, 8),
                            H=HistVectorizer(h, 512, 8)).items()}
-    img = torch.rand(n, 3, S, S)
-    tgt = O.rgbuv_hist(torch.rand(n, 3, S, S), h=h, insz=150)
+    img = torch.rand(n, 3, S, S, device=device)
+    tgt = O.rgbuv_hist(torch.rand(n, 3, S, S, device=device), h=h, insz=150)
 
     def gen(grad):
         with torch.set_grad_enabled(grad):
-            w = N.vectorizer(sd['S'], torch.randn(n, 512), 'net')
+            w = N.vectorizer(sd['S'], torch.randn(n, 512, device=device), 'net')
             hw = N.vectorizer(sd['H'], tgt, 'fcs')
             return N.generator(sd['G'], w[:, None].expand(-1, L - 2, -1), hw[:, None].expand(-1, 2, -1),
-                               torch.rand(n, S, S, 1), L)
+                               torch.rand(n, S, S, 1, device=device), L)
 
     def one_step():
         fake = gen(False)
@@ -182,21 +221,62 @@ def cpu_baseline_train(args):
         loss = N.discriminator(sd['D'], fake, L + 1).mean() + O.hellinger_loss(tgt, O.rgbuv_hist(F.relu(fake), h=h, insz=150), 2.0)
         torch.autograd.grad(loss, [v for k in 'GSH' for v in sd[k].values()], allow_unused=True)
 
-    t0 = time.perf_counter()
-    one_step()
-    dt = time.perf_counter() - t0
-    # optimizer: DiffGrad over every parameter once per step (amortised over the full batch)
     flat = torch.cat([v.detach().reshape(-1) for k in 'GDSH' for v in sd[k].values()])
     state = dict(step=0, exp_avg=torch.zeros_like(flat), exp_avg_sq=torch.zeros_like(flat),
                  previous_grad=torch.zeros_like(flat))
-    t0 = time.perf_counter()
-    N.diffgrad_step(flat, torch.randn_like(flat), state, 2e-4)
-    dto = time.perf_counter() - t0
+
+    def diffgrad_once():
+        N.diffgrad_step(flat, torch.randn_like(flat), state, 2e-4)
+
+    return one_step, diffgrad_once, flat.numel()
+
+
+def _median_time(fn, reps=3, sync=None):
+    """One warm-up call, then the median wall time of `reps` calls."""
+    fn()
+    ts = []
+    for _ in range(reps):
+        if sync:
+            sync()
+        t0 = time.perf_counter()
+        fn()
+        if sync:
+            sync()
+        ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
+def cpu_baseline_train(args):
+    """The oracle doing the compute of one train step on the host cores, on a bounded sample of the batch: one warm-up,
+    then the median of three timings (torch CPU, all threads)."""
+    n = args.cpu_images
+    one_step, diffgrad_once, nparam = oracle_train_step(args, n, torch.device('cpu'))
+    dt = _median_time(one_step)
+    dto = _median_time(diffgrad_once)       # optimizer: DiffGrad over every parameter once per step (amortised over the batch)
     per_img = dt / n + dto / args.batch
     return dict(value=1.0 / per_img, unit='images/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'{n} of the {args.batch} images: one D phase + one G phase (no GP / PL step) {dt:.1f} s, '
-                       f'DiffGrad over {flat.numel()/1e6:.0f} M parameters {dto:.2f} s amortised over the batch; '
-                       f'torch CPU {torch.get_num_threads()} threads')
+                       f'DiffGrad over {nparam/1e6:.0f} M parameters {dto:.2f} s amortised over the batch; '
+                       f'torch CPU {torch.get_num_threads()} threads; 1 warm-up + median of 3')
+
+
+def reference_eager_rocm(args, dev):
+    """'Just run the repo on AMD' (BASELINE.md section 3.4): the reference's op chain -- per-sample modulated weights +
+    one grouped F.conv2d, nn.Upsample, the ~80-launch-per-image histogram chain with fp64 temporaries -- executed by
+    stock PyTorch-ROCm eager (MIOpen / rocBLAS / aten) on the same GPU, same batch, fp32.  Outside the timed region;
+    the operator chain is the oracle's restatement (the reference itself is not on the GPU box)."""
+    n = args.batch
+    try:
+        one_step, diffgrad_once, nparam = oracle_train_step(args, n, dev)
+        dt = _median_time(one_step, reps=1, sync=torch.cuda.synchronize)
+        dto = _median_time(diffgrad_once, reps=1, sync=torch.cuda.synchronize)
+        torch.cuda.empty_cache()
+        return dict(value=n / (dt + dto), unit='images/s', ms_per_step=(dt + dto) * 1e3, batch=n, kind='port',
+                    sample=f'one plain D+G step (no GP / PL) at batch {n}: {dt*1e3:.0f} ms + DiffGrad (aten, {nparam/1e6:.0f} M '
+                           f'parameters) {dto*1e3:.0f} ms; 1 warm-up + 1 timed run; aten/MIOpen/rocBLAS eager, fp32')
+    except Exception as e:      # e.g. out of memory for the materialised per-sample weights at a larger size
+        torch.cuda.empty_cache()
+        return dict(value=None, error=f'{type(e).__name__}: {str(e)[:200]}')
 
 
 def train_workload(args, dev, rank, world):
@@ -210,6 +290,7 @@ def train_workload(args, dev, rank, world):
 
     def step():
         tr.train(alpha=2)
+    step.trainer = tr
 
     info = dict(workload=f'HistoGAN G+D train step {args.size}x{args.size} capacity={args.capacity} '
                          f'batch={args.batch}/GPU h={args.bins} insz=150 inverse-quadratic (GP every 4th, PL every 32nd step)',
@@ -232,6 +313,7 @@ def rehistogan_workload(args, dev, rank, world):
 
     def step():
         tr.train(alpha=32, beta=1.5, gamma=4)
+    step.trainer = tr
 
     n = lambda m: sum(p.numel() for p in m.parameters())
     info = dict(workload=f'ReHistoGAN recolouring train step {args.size}x{args.size} capacity={args.capacity} '
@@ -243,20 +325,52 @@ def rehistogan_workload(args, dev, rank, world):
 
 
 def cpu_baseline(args):
-    """The oracle (port of the reference's PyTorch CPU path) on a bounded sample of the workload."""
+    """The oracle (port of the reference's PyTorch CPU path) on a bounded sample of the workload: one warm-up, median of 3."""
     from oracle import rgbuv_hist as O
     S, h = args.size, args.bins
     nimg = args.cpu_images
     g = torch.Generator().manual_seed(5)
     x = torch.rand(nimg, 3, S, S, generator=g)
     tgt = O.rgbuv_hist(torch.rand(nimg, 3, S, S, generator=g), h=h, insz=S)
-    O.rgbuv_hist_fwd_bwd(x[:1], target=tgt[:1], h=h, insz=S)       # warm-up
-    t0 = time.perf_counter()
-    O.rgbuv_hist_fwd_bwd(x, target=tgt, alpha=2.0, h=h, insz=S)
-    dt = time.perf_counter() - t0
+    dt = _median_time(lambda: O.rgbuv_hist_fwd_bwd(x, target=tgt, alpha=2.0, h=h, insz=S))
     return dict(value=nimg / dt, unit='images/s', cores=torch.get_num_threads(), kind='port',
                 sample=f'{nimg} of the {args.batch} images ({nimg}x3x{S}x{S}), fwd+Hellinger+bwd, torch CPU '
-                       f'{torch.get_num_threads()} threads, {dt:.2f} s')
+                       f'{torch.get_num_threads()} threads, {dt:.2f} s; 1 warm-up + median of 3')
+
+
+def ddp_probe(dist, dev, rank, world, tr):
+    """Self-check of the data-parallel set-up for the driver's SCALE record: every rank reports the world size / backend
+    it sees and its device, and the gradient all-reduces of one step are timed stand-alone (outside the timed region):
+    payload bytes, ms, algorithm bandwidth and bus bandwidth (2 (N-1)/N x payload / time) per collective."""
+    backend = dist.get_backend()
+    seen = [None] * world
+    dist.all_gather_object(seen, dict(rank=rank, world_size=dist.get_world_size(), device=str(dev),
+                                      device_name=torch.cuda.get_device_name(dev)))
+    info = {'backend': backend, 'ranks': seen, 'hellinger': 'global batch (one scalar all-reduce per step)'}
+    if tr is None or getattr(tr, 'GAN', None) is None:
+        return info
+    res = {}
+    for name, flat in (('D', tr.GAN._flat_d), ('G+S+H', tr.GAN._flat_g)):
+        buf = torch.zeros_like(flat.grad)
+        for _ in range(2):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        t = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item())
+        nbytes = buf.numel() * 4
+        res[name] = {'bytes': nbytes, 'ms': ms, 'algbw_GBps': nbytes / ms / 1e6,
+                     'busbw_GBps': 2.0 * (world - 1) / world * nbytes / ms / 1e6}
+        del buf
+    info['allreduce'] = res
+    info['allreduce_ms_per_step'] = sum(v['ms'] for v in res.values())
+    return info
 
 
 def main():
@@ -271,6 +385,7 @@ def main():
     ap.add_argument('--bins', type=int, default=64)
     ap.add_argument('--cpu-images', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-reference-eager', action='store_true')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -301,15 +416,33 @@ def main():
     else:
         step, info = hstep, hinfo
 
+    ddp_info = None
+    if dist:
+        ddp_info = ddp_probe(dist, dev, rank, world, getattr(step, 'trainer', None))
     for _ in range(args.warmup):
         step()
+    tr = getattr(step, 'trainer', None)
+    if tr is not None:
+        # Pin the schedule phase: the timed window starts on a step with steps % 32 == 0, so K timed steps always hold
+        # ceil(K/4) gradient-penalty steps and ceil(K/32) path-length steps (the reference's mix, histoGAN.py:882-883),
+        # whatever --warmup was.  (With K < 32 the one path-length step weighs more than its 1/32 share: the
+        # `schedule_mix` entry below re-weights the measured per-kind means to the 32-step period.)
+        tr.steps = 32 * ((tr.steps + 31) // 32)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    per_step, kinds, host_ms, graphed = [], [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        ts = time.perf_counter()
+        if tr is not None:
+            kinds.append('gp+pl' if tr.steps % 32 == 0 else ('gp' if tr.steps % 4 == 0 else 'plain'))
+        step()                      # (train() ends with its one blocking read-back: the wall time of a call is the step time)
+        per_step.append(time.perf_counter() - ts)
+        if tr is not None:
+            host_ms.append(getattr(tr, 'host_enqueue_ms', float('nan')))
+            graphed.append(bool(getattr(tr, 'last_step_graphed', False)))
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -330,9 +463,14 @@ def main():
     # the HBM-side method of the same block: thresholding on the scatter-add / gather kernels
     tt_f, tt_b = time_kernels(min(max(args.steps, 5), 20), 'thresholding')
     thr_gbps = (work['bytes_fwd'] + work['bytes_bwd']) / (tt_f + tt_b) / 1e9
-    hist_roof['thresholding'] = {'kernels': 'k_hist_thr_fwd + reduce + normalize / k_hist_ghat + k_hist_thr_bwd', 'bound': 'hbm',
+    hist_roof['thresholding'] = {'kernels': 'k_thr_fwd_lean + k_hist_finish / k_thr_bwd_lean', 'bound': 'hbm',
                                  'fwd_ms': tt_f * 1e3, 'bwd_ms': tt_b * 1e3, 'achieved': thr_gbps, 'peak': HBM_PEAK_GBPS,
-                                 'unit': 'GB/s', 'frac': thr_gbps / HBM_PEAK_GBPS}
+                                 'unit': 'GB/s', 'frac': thr_gbps / HBM_PEAK_GBPS,
+                                 'traffic': recorded_value('thr_traffic_bytes_b32') if (args.batch, args.size, args.bins) == (32, 256, 64) else None,
+                                 'note': 'three launches of 17 + 5 + 23 us at batch 32: launch-latency regime (78.6 MB = 9.8 us at peak)'}
+    if rank == 0 and world == 1 and (args.size, args.bins) == (256, 64) and args.batch < 256:
+        # the same kernels where the launches are long enough to stream: batch 256 (629 MB per forward + backward)
+        hist_roof['thresholding']['batch256'] = thr_probe_batch(dev, 256, args.size, args.bins)
     if args.workload in ('train', 'rehistogan'):
         ct = conv_kernel_times(dev, args.batch)
         fl, tf, td, tw = ct[(256, 128, 64)]
@@ -365,9 +503,31 @@ def main():
             'hist_hbm_gbps_algorithmic': (work['bytes_fwd'] + work['bytes_bwd']) / (t_fwd + t_bwd) / 1e9,
             'hist_hbm_frac_of_peak': (work['bytes_fwd'] + work['bytes_bwd']) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBPS,
         }
+        if kinds:
+            mean = lambda k: (sum(t for t, kk in zip(per_step, kinds) if kk == k) / max(1, kinds.count(k))) * 1e3
+            sched = {'gp_steps': sum(k != 'plain' for k in kinds), 'pl_steps': kinds.count('gp+pl'),
+                     'plain_steps': kinds.count('plain'),
+                     'ms_plain': mean('plain') if 'plain' in kinds else None, 'ms_gp': mean('gp') if 'gp' in kinds else None,
+                     'ms_gp_pl': mean('gp+pl') if 'gp+pl' in kinds else None}
+            if all(sched[k] is not None for k in ('ms_plain', 'ms_gp', 'ms_gp_pl')):
+                period = (24 * sched['ms_plain'] + 7 * sched['ms_gp'] + sched['ms_gp_pl']) / 32.0
+                sched['ms_per_step_32_period'] = period
+                sched['images_per_s_32_period'] = units * world / period * 1e3
+            out['schedule_mix'] = sched
+            plain_host = [h for h, k in zip(host_ms, kinds) if k == 'plain']
+            out['host'] = {'enqueue_ms_plain_step': sum(plain_host) / max(1, len(plain_host)),
+                           'enqueue_ms_mean': sum(host_ms) / max(1, len(host_ms)),
+                           'graph_mode': getattr(tr, 'graph_mode', None),
+                           'graph_replayed_steps': int(sum(graphed)),
+                           'launches_per_plain_step_eager': recorded_value('launches_per_plain_step'),
+                           'host_calls_per_graphed_step': 1 if any(graphed) else None}
+        if dist:
+            out['ddp'] = ddp_info
         if world == 1 and not args.no_cpu_baseline:
             if args.workload != 'rehistogan':      # the CPU baseline is quoted for the headline workloads only
                 out['cpu_baseline'] = cpu_baseline_train(args) if args.workload == 'train' else cpu_baseline(args)
+            if args.workload == 'train' and not args.no_reference_eager:
+                out['reference_eager_rocm'] = reference_eager_rocm(args, dev)
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

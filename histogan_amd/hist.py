@@ -202,7 +202,42 @@ class HellingerFunction(torch.autograd.Function):
         return None, grad * gl, None
 
 
-def hellinger_loss(target_hist, gen_hist, alpha=1.0):
+class _GlobalHellinger(torch.autograd.Function):
+    """The Hellinger loss of the GLOBAL batch under data parallelism: the reference takes ONE square root over the whole
+    batch (histoGAN/histoGAN.py:957-960), so the per-rank value sqrt(S_r)/B_r is not a shard of it.  One fp32 all-reduce
+    of S_r = sum (sqrt t - sqrt g)^2 gives every rank D = sqrt(sum_r S_r):
+        loss = alpha/sqrt2 * D / B_global                                  (the same number on every rank)
+        dloss/dg (this rank's samples) = local gradient * (B_r D_r) / (B_global D)
+    and because the gradient all-reduce AVERAGES over ranks, the local gradient is scaled by world * that = D_r / D."""
+
+    @staticmethod
+    def forward(ctx, local_loss, alpha, batch_local):
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        d_local = local_loss.detach() * (2.0 ** 0.5) * batch_local / alpha          # sqrt(S_r)
+        s = (d_local * d_local).reshape(1).clone()
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        d_glob = torch.sqrt(s[0])
+        ctx.scale = d_local / d_glob
+        return alpha / (2.0 ** 0.5) * d_glob / (batch_local * world)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.scale, None, None
+
+
+HELLINGER_LOCAL = __import__('os').environ.get('HG_HELLINGER_LOCAL', '0') != '0'
+
+
+def hellinger_loss(target_hist, gen_hist, alpha=1.0, global_batch=None):
     """alpha/sqrt(2) * sqrt(sum((sqrt(t)-sqrt(g))^2)) / B  (histoGAN/histoGAN.py:957-960).
-    Gradient flows to gen_hist only (the reference's d/d target is computed and never used)."""
-    return HellingerFunction.apply(target_hist, gen_hist, alpha)
+    Gradient flows to gen_hist only (the reference's d/d target is computed and never used).
+    global_batch: under data parallelism, evaluate the formula on the global batch (one scalar all-reduce; default when
+    a process group with more than one rank is initialised, HG_HELLINGER_LOCAL=1 for the per-shard formula)."""
+    loss = HellingerFunction.apply(target_hist, gen_hist, alpha)
+    if global_batch is None:
+        from . import ddp
+        global_batch = ddp.is_dist() and not HELLINGER_LOCAL
+    if global_batch:
+        loss = _GlobalHellinger.apply(loss, float(alpha), int(gen_hist.shape[0]))
+    return loss

@@ -280,10 +280,12 @@ def test_train_step_matches_oracle(gpu_device, tmp_path):
     # generator-side gradients are still in the flat buffer (zeroed at the start of the next step)
     for (p, k), gr in zip(keys, ggr):
         mine = dict(getattr(GAN, p).named_parameters())[k].grad.detach().cpu().numpy()
-        # 1e-2: d hist / d x = .../(x + 1e-6) is ill-conditioned for the few generated pixels that land
-        # within ~1e-5 of the relu/clamp edge, where 1e-7 differences between two fp32 generator
-        # evaluations change that pixel's gradient by several % (measured worst tensor: 1.1e-3)
-        assert relmax(mine, gr.numpy()) <= 1e-2, (p, k)
+        # 3e-3 (measured worst tensor: 1.1e-3).  The histogram's own per-pixel gradient matches the reference at 1e-4
+        # on generator-like images incl. every clamp-edge pixel (tests/test_hist_big_gpu.py, golden trainer_2x256to150);
+        # what is left here is that two fp32 evaluations of the GENERATOR differ by ~1e-7, and d hist / d x =
+        # .../(x + 1e-6) turns that into a several-% change of the gradient of the few pixels within ~1e-5 of the
+        # relu/clamp edge, which every parameter gradient sums over.
+        assert relmax(mine, gr.numpy()) <= 3e-3, (p, k)
     # parameters after the step.  The first DiffGrad step is ~ lr*sigmoid(|g|)*g/(|g|+3e-8): compare the
     # deltas where the gradient is not rounding noise (elsewhere the sign itself is ill-conditioned)
     for (p, s), grads in ((('D', sD), dict(zip(dk, dgr))),) + tuple(
