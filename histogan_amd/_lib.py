@@ -32,6 +32,7 @@ class HgHistParams(ctypes.Structure):
         ('green_only', ctypes.c_int32),
         ('projection', ctypes.c_int32),
         ('pre_relu', ctypes.c_int32),
+        ('proj_cache', ctypes.c_void_p),
     ]
 
 

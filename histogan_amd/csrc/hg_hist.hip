@@ -35,6 +35,9 @@
 #ifndef HG_FWD_VALU_PER_MFMA
 #define HG_FWD_VALU_PER_MFMA 4
 #endif
+#ifndef HG_FWD_MFMA_GROUP
+#define HG_FWD_MFMA_GROUP 12  // k_hist_fwd at configs[1]: groups of 1: 505 us, 3: 498, 6: 473, 12: 465
+#endif
 #ifndef HG_BWD_SCHED_GROUPS
 #define HG_BWD_SCHED_GROUPS 1
 #endif
@@ -57,6 +60,7 @@ struct DevParams {
   int h, P, method, intensity, green;
   int proj;                 // HG_PROJ_*: 0 RGB-uv (3 planes), 1 rg-chroma, 2 direct (Lab): one plane, run as `green`
   int pre_relu;             // the caller's F.relu in front of the block (histoGAN.py:955) folded into the clamp mask
+  float4 *cache;            // optional [B][npix][2] float4: (a, b, c, Iy), (r, g, b, -) written by the forward, read by the backward
   int npix;
   double lo, hi, step;      // bins: i*step+lo, last == hi  (np.linspace)
   double inv_sigma_d;       // (double)(float)(1/sigma) -- pairs with inv_sigma
@@ -145,6 +149,23 @@ __device__ __forceinline__ void project(const DevParams &P, float r, float g, fl
   a = __fsub_rn(lr, lg); bb = __fsub_rn(lr, lb); c = __fsub_rn(lg, lb);
   // pow(I,2) summed left to right in fp32, no fma contraction (RGBuvHistBlock.py:105-108)
   iy = P.intensity ? __fsqrt_rn(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(r, r), __fmul_rn(g, g)), __fmul_rn(b, b)), kEps)) : 1.f;
+}
+
+// Per-pixel state of the backward kernels: from the forward's cache (two 16-byte loads) or recomputed (up to 12 taps of
+// the bilinear resize + three fp64 logarithms: ~370 VALU instructions per pixel that the MFMA-bound kernels pay for in
+// matrix-pipe time -- fp32 MFMA and VALU instructions do not overlap on gfx950, tools/ubench/mfma_valu_overlap.hip).
+__device__ __forceinline__ void pixel_state(const DevParams &P, const float *xb, int b, int n, bool valid, float &r,
+                                            float &g, float &bl, float &a, float &bb, float &c, float &iy) {
+  if (P.cache) {
+    const float4 *cp = P.cache + ((long long)b * P.npix + (valid ? n : 0)) * 2;
+    const float4 u = cp[0], v = cp[1];
+    a = u.x; bb = u.y; c = u.z; iy = u.w; r = v.x; g = v.y; bl = v.z;
+    if (!valid) { r = g = bl = 0.f; project(P, r, g, bl, a, bb, c, iy); }
+    return;
+  }
+  r = g = bl = 0.f;
+  if (valid) sample_rgb(P, xb, n, r, g, bl);
+  project(P, r, g, bl, a, bb, c, iy);
 }
 
 struct BinC { float chi, clo; double bd; };
@@ -248,6 +269,11 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
     project(P, r_, g_, b_, a, bb, c, iy);
     const bool valid = base + lane < end;
     stage[wave * 64 + lane] = valid ? make_float4(a, bb, c, iy) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.cache && valid && blockIdx.y == 0) {          // one writer per pixel (the bin-block replicas skip it)
+      float4 *cp = P.cache + ((long long)b * P.npix + base + lane) * 2;
+      cp[0] = make_float4(a, bb, c, iy);
+      cp[1] = make_float4(r_, g_, b_, 0.f);
+    }
     // prefetch the next 64 pixels while this batch is in the MFMA loop
     if (base + 64 + lane < end) sample_rgb(P, xb, base + 64 + lane, r_, g_, b_);
     lds_wave_sync();
@@ -273,11 +299,16 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
           if (!green) acc[2][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A2[ti], cur.B2[tj], acc[2][ti][tj], 0, 0, 0);
         }
 #if HG_FWD_SCHED_GROUPS
+      // MFMAs in groups of HG_FWD_MFMA_GROUP with the operand generation of the next step between the groups.  On
+      // gfx950 the fp32 MFMA does not hide VALU work (same issue path: tools/ubench/mfma_valu_overlap.hip -- 3 VALU
+      // instructions per MFMA cost 0.79 of peak interleaved 1:3 and 0.86 as 6 MFMAs : 18 VALU), so what is left to
+      // schedule is the number of MFMA <-> VALU switches.
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      constexpr int NM = (green ? 1 : 3) * T * T, GRP = HG_FWD_MFMA_GROUP < NM ? HG_FWD_MFMA_GROUP : NM;
 #pragma unroll
-      for (int i = 0; i < (green ? 1 : 3) * T * T; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, HG_FWD_VALU_PER_MFMA, 0);
+      for (int i = 0; i < NM; i += GRP) {
+        __builtin_amdgcn_sched_group_barrier(0x008, GRP, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, HG_FWD_VALU_PER_MFMA * GRP, 0);
       }
 #endif
       // pin: q2 is complete here (after a step's worth of MFMA issue), and is next iteration's q1
@@ -475,10 +506,8 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
     if (n0 >= P.npix) break;
     const int n = (int)n0 + q;
     const bool valid = n < P.npix;
-    float r_ = 0.f, g_ = 0.f, b_ = 0.f;
-    if (valid) sample_rgb(P, xb, n, r_, g_, b_);
-    float a, bb, c, iy;
-    project(P, r_, g_, b_, a, bb, c, iy);
+    float r_, g_, b_, a, bb, c, iy;
+    pixel_state(P, xb, b, n, valid, r_, g_, b_, a, bb, c, iy);
 
     // t_s = (u - lo - 4*half*step)/sigma - beta0(s)*step/sigma, double-single
     float th[3], tl[3];
@@ -502,12 +531,7 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
     };
 
     f32x16 W[3][T];
-#pragma unroll
-    for (int v = 0; v < 3; ++v)
-#pragma unroll
-      for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) W[v][t][r] = 0.f;
+    // (no zero fill: the first K step's MFMAs take an inline-constant 0 as their C operand -- 48*T v_mov per round less)
 
     // Kernel values are generated just in time (3 evaluations per 6*T MFMAs) and NOT kept: the
     // epilogue re-evaluates them bit-identically, which keeps the kernel at W (48*T regs) + temporaries
@@ -551,8 +575,34 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
     };
     BOps<T> cur;
     make_bops(0, cur);
+    {                                        // K step 0, peeled: C = 0
+      BOps<T> nxt;
+      make_bops(1, nxt);
+      const f32x16 Z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int rt = 0; rt < T; ++rt) {
+        if (!green) {
+          W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][0], cur.kb, Z, 0, 0, 0);
+          W[1][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][1], cur.ka, Z, 0, 0, 0);
+          W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][2], cur.kb, Z, 0, 0, 0);
+          W[1][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][3], cur.kc, W[1][rt], 0, 0, 0);
+          W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][4], cur.kc, W[0][rt], 0, 0, 0);
+          W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][5], cur.ka, W[2][rt], 0, 0, 0);
+        } else {
+          W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][4], cur.kc, Z, 0, 0, 0);
+          W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][5], cur.ka, Z, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) W[1][rt][r] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < T; ++rt)
+#pragma unroll
+        for (int i = green ? 4 : 0; i < 6; ++i) asm volatile("" : "+v"(nxt.A[rt][i]));
+      cur = nxt;
+    }
 #pragma unroll 1
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 1; s < NS; ++s) {
       BOps<T> nxt;
       make_bops(min(s + 1, NS - 1), nxt);  // LDS reads + 3 kernel evaluations for the next K step
 #pragma unroll
@@ -669,10 +719,8 @@ __global__ __launch_bounds__(256, 2) void k_hist_bwd_planes(const DevParams P, c
       if (n0 >= P.npix) break;
       const int n = (int)n0 + q;
       const bool valid = n < P.npix;
-      float r_ = 0.f, g_ = 0.f, b_ = 0.f;
-      if (valid) sample_rgb(P, xb, n, r_, g_, b_);
-      float a, bb, c, iy;
-      project(P, r_, g_, b_, a, bb, c, iy);
+      float r_, g_, b_, a, bb, c, iy;
+      pixel_state(P, xb, b, n, valid, r_, g_, b_, a, bb, c, iy);
       const float u = (p == 0) ? a : (p == 1 ? -a : -bb), v = (p == 0) ? bb : (p == 1 ? c : -c);
 
       // t_s = (u - lo - 4*half*step)/sigma - beta0(s)*step/sigma, double-single (beta0(s) < 128: beta0*ds_hi exact)
@@ -1759,6 +1807,7 @@ DevParams make_dev(const hg_hist_params *p) {
   d.Hs = p->Hs; d.Ws = p->Ws; d.mode = p->resize_mode; d.rows = p->row_idx; d.cols = p->col_idx;
   d.proj = p->projection;
   d.pre_relu = p->pre_relu ? 1 : 0;
+  d.cache = (float4 *)p->proj_cache;
   d.h = p->h; d.P = (p->green_only || p->projection) ? 1 : 3; d.method = p->method;
   d.intensity = p->intensity_scale ? 1 : 0; d.green = (p->green_only || p->projection) ? 1 : 0;
   d.npix = p->Hs * p->Ws;

@@ -13,6 +13,7 @@ from . import _lib
 from ._lib import HgHistParams, check, lib
 
 _IDX_CACHE = {}
+PROJ_CACHE = __import__('os').environ.get('HG_PROJ_CACHE', '1') != '0'   # A/B switch of the forward->backward projection cache
 
 
 def _sampling_idx(size, h, device):
@@ -105,6 +106,13 @@ class RGBuvHistFunction(torch.autograd.Function):
         ctx.pre_relu = pre_relu
         fwd_b, _ = _ws_bytes(p)
         with torch.cuda.device(x.device):
+            # per-pixel projection cache for the backward (32 B per histogram pixel): only when a gradient will be asked
+            # for, only for the smooth kernels (the scatter paths re-classify pixels cheaply)
+            cache = None
+            if ctx.needs_input_grad[0] and cfg.method != 'thresholding' and PROJ_CACHE:
+                cache = torch.empty((p.B, p.Hs * p.Ws, 8), dtype=torch.float32, device=x.device)
+                p.proj_cache = cache.data_ptr()
+            ctx.cache = cache
             P = 1 if (cfg.green_only or cfg.projection != 'rgbuv') else 3
             out = torch.empty((p.B, P, cfg.h, cfg.h), dtype=torch.float32, device=x.device)
             sums = torch.empty((p.B,), dtype=torch.float32, device=x.device)
@@ -121,6 +129,8 @@ class RGBuvHistFunction(torch.autograd.Function):
         x, out, sums = ctx.saved_tensors
         cfg = ctx.cfg
         p, keep = _make_params(x, cfg, ctx.pre_relu)
+        if ctx.cache is not None:
+            p.proj_cache = ctx.cache.data_ptr()
         _, bwd_b = _ws_bytes(p)
         g = grad_out.detach()
         if g.dtype != torch.float32:

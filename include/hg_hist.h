@@ -67,6 +67,11 @@ typedef struct hg_hist_params {
   /* 1: the F.relu the train step puts in front of the block (histoGAN/histoGAN.py:955) is part of the call -- identical
    * forward (clamp(relu(x)) == clamp(x)); the backward masks x <= 0 instead of x < 0.  Saves that aten launch and node. */
   int32_t pre_relu;
+  /* Optional device buffer of B * Hs * Ws * 32 bytes (16-byte aligned), or NULL.  The forward stores every pixel's
+   * projection (log-chroma differences, weight, clamped / resized colour) there; a backward call given the SAME
+   * buffer reads it instead of re-sampling and re-projecting (bilinear taps + three fp64 logarithms per pixel).
+   * Smooth kernels (inverse-quadratic, dense RBF) only; the scatter paths ignore it. */
+  void *proj_cache;
 } hg_hist_params;
 
 /* library / build identification */

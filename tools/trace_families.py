@@ -22,7 +22,7 @@ def short(n):
 
 steps = float(sys.argv[2])
 a = load(sys.argv[1], steps)
-b = load(sys.argv[3], steps) if len(sys.argv) > 3 else {}
+b = load(sys.argv[3], steps) if len(sys.argv) > 3 and sys.argv[3] not in ('', '-') else {}
 keys = sorted(set(a) | set(b), key=lambda k: -(a.get(k, (0, 0))[1] - b.get(k, (0, 0))[1]))
 ta, tb = sum(v[1] for v in a.values()), sum(v[1] for v in b.values())
 print(f'total ms/step: {ta:.2f}' + (f' vs {tb:.2f} (diff {ta-tb:.2f})' if b else ''))
