@@ -65,6 +65,9 @@ def hist_workload(args, dev, rank, world):
         gx = torch.empty_like(xd)
         gout = torch.rand(B, 3, h, h, device=dev) - 0.5
         ws = torch.empty(max(fb, bb, 4), dtype=torch.uint8, device=dev)
+        if method is None:      # the forward -> backward projection cache the autograd Function passes (hist.py)
+            cache = torch.empty(B, S * S, 8, device=dev)
+            p.proj_cache = cache.data_ptr()
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
         for it in range(iters + 2):
