@@ -1237,6 +1237,21 @@ __global__ __launch_bounds__(256) void k_hist_thr_bwd(const DevParams P, const f
     for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
 }
 
+// XCD-aware (image, slice) of a workgroup in a (S, B) grid.  Block L = y*S + x runs on XCD L % 8 (observed placement;
+// a wrong guess is slower, never wrong): with the plain mapping the S workgroups of one image sit on S different XCDs,
+// and every XCD's (non-coherent) L2 fetches that image's G / hist / slabs for itself -- measured at batch 32:
+// 24 MB of the thresholding backward's 49 MB of fabric reads.  Here the blocks of one XCD take whole images:
+// per-XCD index j -> (image (j / S) * 8 + xcd, slice j % S).  Needs B % 8 == 0; identity otherwise.
+__device__ __forceinline__ void xcd_image_slice(int B, int &b, int &s) {
+  const int S = gridDim.x;
+  b = blockIdx.y; s = blockIdx.x;
+  if ((B & 7) == 0) {
+    const int L = blockIdx.y * S + blockIdx.x, xcd = L & 7, j = L >> 3;
+    s = j % S;
+    b = (j / S) * 8 + xcd;
+  }
+}
+
 // ---- lean scatter kernels: RGB-uv, three planes, `single` windows, all three grids in LDS ----------------------------
 // The configuration every default-constructed RGBuvHistBlock(method='thresholding') has.  DIRECT: no resize and
 // contiguous planes -> 16-byte loads / stores, four pixels per thread and iteration; otherwise sample_rgb (bilinear /
@@ -1255,7 +1270,9 @@ __global__ __launch_bounds__(1024) void k_thr_fwd_lean(const DevParams P, const 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned long long sm_tot[16];
   unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem);   // [3][h][h]
-  const int b = blockIdx.y, s = blockIdx.x, S = gridDim.x, h = P.h, hh = h * h;
+  const int S = gridDim.x, h = P.h, hh = h * h;
+  int b, s;
+  xcd_image_slice(P.B, b, s);
   const float *xb = x + (long long)b * P.sb;
   const int n0 = s * per_block, n1 = min(P.npix, n0 + per_block);
   const double inv_step = 1.0 / P.step;
@@ -1352,10 +1369,12 @@ __global__ __launch_bounds__(1024) void k_thr_bwd_lean(const DevParams P, const 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float sm16[16];
   float *gh = reinterpret_cast<float *>(smem);         // Ghat [3][h][h]: the per-pixel gathers hit LDS, not L2
-  const int b = blockIdx.y, h = P.h, hh = h * h, nel = 3 * hh;
+  const int h = P.h, hh = h * h, nel = 3 * hh;
+  int b, sl;
+  xcd_image_slice(P.B, b, sl);
   const float *g = gout + (long long)b * nel, *o = hist + (long long)b * nel;
   const float *xb = x + (long long)b * P.sb;
-  const int n0 = blockIdx.x * per_block, n1 = min(P.npix, n0 + per_block);
+  const int n0 = sl * per_block, n1 = min(P.npix, n0 + per_block);
   // the first tile's loads are in flight during the <G, out> prologue
   float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = r4, b4 = r4;
   int n = n0 + 4 * threadIdx.x;
