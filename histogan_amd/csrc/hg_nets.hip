@@ -9,6 +9,7 @@
 //   epilogue  k_demod_noise_lrelu: lrelu(conv*d + noise)                   (+ adjoint, + dL/dd, dL/dnoise-params)
 // plus the fused flat-buffer DiffGrad step and EMA.  All HBM-bound: one read + one write per element.
 #include "hg_common.h"
+#include <cstdlib>
 #include "../../include/hg_hist.h"
 #include "../../include/hg_nets.h"
 
@@ -359,7 +360,8 @@ extern "C" {
 
 // chunks per plane for the partial-sum kernels: ~1024 blocks in total, each thread >= 4 vector iterations
 static inline int plane_chunks(long long planes, long long vec_per_plane) {
-  long long c = (1024 + planes - 1) / planes;
+  static const long long target = [] { const char *e = getenv("HG_NETS_BLOCKS"); return e && atoll(e) > 0 ? atoll(e) : 1024LL; }();
+  long long c = (target + planes - 1) / planes;
   const long long cmax = (vec_per_plane + 1023) / 1024;   // >= 4 iterations of 256 threads
   if (c > cmax) c = cmax;
   if (c < 1) c = 1;
