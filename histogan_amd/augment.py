@@ -12,7 +12,7 @@ from random import random
 import torch
 from torch import nn
 
-from ._lib import check, lib
+from ._lib import check, lib, on_device, raw_stream
 from .ops import _f32c, _need_gpu, _st
 
 NP = 9                                    # HG_AUG_NP
@@ -25,7 +25,7 @@ class _Spatial(torch.autograd.Function):
         _need_gpu(x, 'DiffAugment')
         x = _f32c(x.detach())
         B, C, H, W = x.shape
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             out = torch.empty_like(x)
             check(lib.hg_augment_spatial(x.data_ptr(), params.data_ptr(), out.data_ptr(), B, C, H, W, int(adjoint),
                                          _st(x)), 'hg_augment_spatial')
@@ -52,7 +52,7 @@ class _Color(torch.autograd.Function):
         _need_gpu(x, 'DiffAugment')
         x = _f32c(x.detach())
         B, C, H, W = x.shape
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             out = torch.empty_like(x)
             check(lib.hg_augment_color(x.data_ptr(), _sample_mean(x).data_ptr(), color.data_ptr(), out.data_ptr(), B, C,
                                        H * W, int(adjoint), _st(x)), 'hg_augment_color')

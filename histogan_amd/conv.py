@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from ._lib import check, lib
+from ._lib import check, lib, on_device, raw_stream
 
 PACK_FWD, PACK_DGRAD = 0, 1
 _skip_wgrad = False
@@ -46,7 +46,7 @@ def input_grads_only():
 
 
 def _st(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return raw_stream(t.device)
 
 
 def _f32c(t):
@@ -172,7 +172,7 @@ def pack_b6(w, mode):
     def make(t):
         Co, Ci = t.shape[0], t.shape[1]
         nbytes = lib.hg_conv_b6_packed_bytes(Co, Ci, mode)
-        with torch.cuda.device(t.device):
+        with on_device(t.device):
             wt = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
             check(lib.hg_conv_b6_pack_weights(t.data_ptr(), wt.data_ptr(), Co, Ci, mode, _st(t)), 'hg_conv_b6_pack_weights')
         return wt
@@ -181,7 +181,7 @@ def pack_b6(w, mode):
 
 def conv_b6(x, wt, N, bias=None):
     B, K, H, W = x.shape
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
         check(lib.hg_conv2d_b6(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(bias), B, K, N, H, W, _st(x)), 'hg_conv2d_b6')
     return out
@@ -189,7 +189,7 @@ def conv_b6(x, wt, N, bias=None):
 
 def _pack_both(w):
     Co, Ci, k, _ = w.shape
-    with torch.cuda.device(w.device):
+    with on_device(w.device):
         wf = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_FWD), dtype=torch.float32, device=w.device)
         wd = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_DGRAD), dtype=torch.float32, device=w.device)
         check(lib.hg_conv_pack_weights_both(w.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, _st(w)),
@@ -202,7 +202,7 @@ def _pack_weights(w, mode):
     n = lib.hg_conv_packed_elems(Co, Ci, k, mode)
     if n == 0:
         raise ValueError(f'conv weights {tuple(w.shape)}: only square 1x1 / 3x3 kernels are implemented')
-    with torch.cuda.device(w.device):
+    with on_device(w.device):
         wt = torch.empty(n, dtype=torch.float32, device=w.device)
         check(lib.hg_conv_pack_weights(w.data_ptr(), wt.data_ptr(), Co, Ci, k, mode, _st(w)), 'hg_conv_pack_weights')
     return wt
@@ -211,7 +211,7 @@ def _pack_weights(w, mode):
 def conv_fwd_packed(x, wt, N, ksize, stride=1, iscale=None, oscale=None, bias=None):
     """out[b,n] = oscale[b,n] * sum_k conv(iscale[b,k] * x[b,k], Wt[.,k,n]) + bias[n]   (x: (B,K,H,W) contiguous)."""
     B, K, H, W = x.shape
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         out = torch.empty((B, N, _out_size(H, stride), _out_size(W, stride)), dtype=torch.float32, device=x.device)
         nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, stride, 0)
         ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
@@ -223,7 +223,7 @@ def conv_fwd_packed(x, wt, N, ksize, stride=1, iscale=None, oscale=None, bias=No
 def conv_dgrad_packed(g, wt, N, H, W, ksize, stride=1, iscale=None, oscale=None):
     """Data gradient: g (B,K,Ho,Wo) -> (B,N,H,W); wt packed with PACK_DGRAD."""
     B, K = g.shape[:2]
-    with torch.cuda.device(g.device):
+    with on_device(g.device):
         gin = torch.empty((B, N, H, W), dtype=torch.float32, device=g.device)
         nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, stride, 1)
         ws = torch.empty(nb, dtype=torch.uint8, device=g.device) if nb else None
@@ -237,7 +237,7 @@ def conv_wgrad(x, gout, ksize, stride=1, iscale=None, gscale=None, out=None):
     out: optional contiguous (N,K,k,k) tensor to write (e.g. the weight's slice of a flat gradient buffer)."""
     B, K, H, W = x.shape
     N = gout.shape[1]
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         nbytes = lib.hg_conv2d_wgrad_workspace_bytes(B, K, N, H, W, ksize, stride)
         ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=x.device)
         gw = out if out is not None else torch.empty((N, K, ksize, ksize), dtype=torch.float32, device=x.device)
@@ -422,7 +422,7 @@ class _ConvLrelu(torch.autograd.Function):
         N, k = w.shape[0], w.shape[2]
         wt = pack_weights(wc, PACK_FWD)
         bc = None if bias is None else _f32c(bias)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             out = torch.empty((B, N, _out_size(H, stride), _out_size(W, stride)), dtype=torch.float32, device=x.device)
             if stride == 1:
                 nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, k, 1, 0)

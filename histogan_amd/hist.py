@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import HgHistParams, check, lib
+from ._lib import HgHistParams, check, lib, on_device, raw_stream
 
 _IDX_CACHE = {}
 PROJ_CACHE = __import__('os').environ.get('HG_PROJ_CACHE', '1') != '0'   # A/B switch of the forward->backward projection cache
@@ -87,7 +87,7 @@ def _ws_bytes(p):
 
 
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return raw_stream(device)
 
 
 def _require_gpu(x, what):
@@ -105,7 +105,7 @@ class RGBuvHistFunction(torch.autograd.Function):
         p, keep = _make_params(x, cfg, pre_relu)
         ctx.pre_relu = pre_relu
         fwd_b, _ = _ws_bytes(p)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             # per-pixel projection cache for the backward (32 B per histogram pixel): only when a gradient will be asked
             # for, only for the smooth kernels (the scatter paths re-classify pixels cheaply)
             cache = None
@@ -136,7 +136,7 @@ class RGBuvHistFunction(torch.autograd.Function):
         if g.dtype != torch.float32:
             g = g.float()
         g = g.contiguous()
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             gx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
             ws = torch.empty((max(bwd_b, 4),), dtype=torch.uint8, device=x.device)
             check(lib.hg_rgbuv_hist_bwd(ctypes.byref(p), x.data_ptr(), g.data_ptr(), out.data_ptr(),
@@ -195,7 +195,7 @@ class HellingerFunction(torch.autograd.Function):
         if t.shape != g.shape:
             raise ValueError(f'shape mismatch {tuple(t.shape)} vs {tuple(g.shape)}')
         n = g.numel()
-        with torch.cuda.device(g.device):
+        with on_device(g.device):
             loss = torch.empty((), dtype=torch.float32, device=g.device)
             grad = torch.empty_like(g)
             wsb = lib.hg_hellinger_workspace_bytes(n)

@@ -8,11 +8,11 @@ import ctypes
 
 import torch
 
-from ._lib import check, lib
+from ._lib import check, lib, on_device, raw_stream
 
 
 def _st(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return raw_stream(t.device)
 
 
 def _f32c(t):
@@ -29,7 +29,7 @@ def channel_sum(g):
     """(B, C, H, W) -> (C): sum over batch and pixels (bias gradient), deterministic two-stage reduction."""
     g = _f32c(g.detach())
     B, C, H, W = g.shape
-    with torch.cuda.device(g.device):
+    with on_device(g.device):
         out = torch.empty(C, dtype=torch.float32, device=g.device)
         ws, n = _ws(g, B, C, H, W)
         check(lib.hg_channel_sum(g.data_ptr(), out.data_ptr(), B, C, H * W, ws.data_ptr(), n, _st(g)), 'hg_channel_sum')
@@ -49,7 +49,7 @@ class _Modulate(torch.autograd.Function):
         s = None if s is None else _f32c(s.detach())
         B, C, H, W = x.shape
         f = 2 if upsample else 1
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             out = torch.empty((B, C, H * f, W * f), dtype=torch.float32, device=x.device)
             check(lib.hg_modulate_fwd(x.data_ptr(), None if s is None else s.data_ptr(), out.data_ptr(),
                                       B, C, H, W, int(upsample), _st(x)), 'hg_modulate_fwd')
@@ -62,7 +62,7 @@ class _Modulate(torch.autograd.Function):
         x, s = ctx.saved_tensors
         g = _f32c(g.detach())
         B, C, H, W = x.shape
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             gx = torch.empty_like(x)
             gs = None if s is None else torch.empty_like(s)
             ws, n = _ws(x, B, C, H, W)
@@ -93,7 +93,7 @@ class _DemodNoiseLrelu(torch.autograd.Function):
         if H != W:
             raise ValueError('square feature maps only (the noise permute of the reference needs H == W)')
         S = nzt.shape[-1]
-        with torch.cuda.device(conv.device):
+        with on_device(conv.device):
             out = torch.empty_like(conv)
             check(lib.hg_demod_noise_lrelu_fwd(conv.data_ptr(), None if d is None else d.data_ptr(), nzt.data_ptr(),
                                                wn.data_ptr(), bn.data_ptr(), out.data_ptr(), B, O, H, S, _st(conv)),
@@ -108,7 +108,7 @@ class _DemodNoiseLrelu(torch.autograd.Function):
         g = _f32c(g.detach())
         B, O, H, _ = conv.shape
         S = nzt.shape[-1]
-        with torch.cuda.device(conv.device):
+        with on_device(conv.device):
             gconv = torch.empty_like(conv)
             gd = None if d is None else torch.empty_like(d)
             gw = torch.empty((B, O), dtype=torch.float32, device=conv.device)
@@ -147,7 +147,7 @@ class _ModConvStage(torch.autograd.Function):
         N, _, k, _ = w.shape
         s1 = style + 1.0
         if upsample:
-            with torch.cuda.device(x.device):
+            with on_device(x.device):
                 xin = torch.empty((B, K, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
                 check(lib.hg_modulate_fwd(x.data_ptr(), style.data_ptr(), xin.data_ptr(), B, K, H, W, 1, _st(x)),
                       'hg_modulate_fwd')
@@ -166,7 +166,7 @@ class _ModConvStage(torch.autograd.Function):
             nzt_ = wn_ = bn_ = None
             S = 0
         wt = C.pack_weights(w, C.PACK_FWD)
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             out = torch.empty((B, N, Hi, Wi), dtype=torch.float32, device=x.device)
             nb = lib.hg_conv2d_workspace_bytes(B, K, N, Hi, Wi, k, 1, 0)
             ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
@@ -191,7 +191,7 @@ class _ModConvStage(torch.autograd.Function):
             xin = x
         Hi, Wi = xin.shape[2], xin.shape[3]
         gwn = gbn = gd = None
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             if act:
                 S = nzt_.shape[-1]
                 gconv = torch.empty_like(out)

@@ -10,12 +10,12 @@ import ctypes
 
 import torch
 
-from ._lib import check, lib
+from ._lib import check, lib, on_device, raw_stream
 from .conv import weights_changed
 
 
 def _st(t):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return raw_stream(t.device)
 
 
 class FlatParams:
@@ -128,7 +128,7 @@ class DiffGrad:
         if not f.data.is_cuda:
             raise RuntimeError('DiffGrad: parameters are not on a GPU; no CPU implementation')
         if self.graph_mode:           # being captured: step size from device memory, counter advanced by prepare_replay()
-            with torch.cuda.device(f.data.device):
+            with on_device(f.data.device):
                 check(lib.hg_diffgrad_step_dev(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
                                                self.exp_avg_sq.data_ptr(), self.previous_grad.data_ptr(), f.numel,
                                                self._step_size_dev.data_ptr(), float(self.betas[0]),
@@ -138,7 +138,7 @@ class DiffGrad:
             return
         self.step_count += 1
         lr = self.param_groups[0]['lr']
-        with torch.cuda.device(f.data.device):
+        with on_device(f.data.device):
             check(lib.hg_diffgrad_step(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
                                        self.exp_avg_sq.data_ptr(), self.previous_grad.data_ptr(), f.numel,
                                        float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
@@ -150,7 +150,7 @@ def ema_update(ma_flat, cur_flat, beta):
     """ma = beta*ma + (1-beta)*cur over two FlatParams with identical layout (HistoGAN.EMA)."""
     if ma_flat.numel != cur_flat.numel:
         raise ValueError('EMA buffers differ in size')
-    with torch.cuda.device(ma_flat.data.device):
+    with on_device(ma_flat.data.device):
         check(lib.hg_ema_update(ma_flat.data.data_ptr(), cur_flat.data.data_ptr(), ma_flat.numel, float(beta),
                                 _st(ma_flat.data)), 'hg_ema_update')
     weights_changed(ma_flat.data)

@@ -12,7 +12,7 @@ import ctypes
 
 import torch
 
-from ._lib import check, lib
+from ._lib import check, lib, on_device, raw_stream
 from .ops import _f32c, _need_gpu, _st
 
 
@@ -27,7 +27,7 @@ class _InstNormLrelu(torch.autograd.Function):
         _need_gpu(x, 'instnorm_lrelu')
         x = _f32c(x.detach())
         B, C, H, W = x.shape
-        with torch.cuda.device(x.device):
+        with on_device(x.device):
             out = torch.empty_like(x)
             stats = torch.empty((B * C, 2), dtype=torch.float32, device=x.device)
             ws, n = _in_ws(x, B * C)
@@ -42,7 +42,7 @@ class _InstNormLrelu(torch.autograd.Function):
         out, stats = ctx.saved_tensors
         g = _f32c(g.detach())
         B, C, H, W = out.shape
-        with torch.cuda.device(out.device):
+        with on_device(out.device):
             gx = torch.empty_like(out)
             ws, n = _in_ws(out, B * C)
             check(lib.hg_instnorm_lrelu_bwd(g.data_ptr(), out.data_ptr(), stats.data_ptr(), gx.data_ptr(), B * C, H * W,
@@ -60,7 +60,7 @@ def _stencil_raw(x, taps, C, adjoint):
     x = _f32c(x.detach())
     B, _, H, W = x.shape
     arr = (ctypes.c_float * 9)(*[float(v) for v in taps])
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         out = torch.empty((B, C if adjoint else 1, H, W), dtype=torch.float32, device=x.device)
         check(lib.hg_stencil3(x.data_ptr(), out.data_ptr(), arr, B, C, H, W, int(adjoint), _st(x)), 'hg_stencil3')
     return out
@@ -90,7 +90,7 @@ def _dw_raw(x, k, H, W, adjoint):
     x = _f32c(x.detach())
     B, C = x.shape[:2]
     KS = k.shape[-1]
-    with torch.cuda.device(x.device):
+    with on_device(x.device):
         shape = (B, C, H, W) if adjoint else (B, C, H - KS + 1, W - KS + 1)
         out = torch.empty(shape, dtype=torch.float32, device=x.device)
         check(lib.hg_depthwise_valid(x.data_ptr(), k.data_ptr(), out.data_ptr(), B * C, H, W, KS, int(adjoint), _st(x)),
