@@ -116,21 +116,25 @@ SPATIAL = ('offset', 'offset_h', 'offset_v', 'translation', 'cutout')
 _RANK = {'flip': 0, 'offset': 1, 'offset_h': 1, 'offset_v': 1, 'translation': 2, 'cutout': 3}
 
 
-def _spatial_run(x, names, flip=None, generator=None):
-    """One launch for `names` (non-decreasing _RANK order, each rank at most once), optionally preceded by a flip."""
+def _spatial_run(x, names, flip=None, generator=None, ratios=None):
+    """One launch for `names` (non-decreasing _RANK order, each rank at most once), optionally preceded by a flip.
+    ratios: optional {name: dict of the reference function's ratio arguments} (defaults: utils/diff_augment.py)."""
     B, _, H, W = x.shape
+    ratios = ratios or {}
     p = torch.tensor(_ID, dtype=torch.int32).repeat(B, 1)
     if flip is not None:
         p[:, 0] = flip
     for n in names:
+        kw = ratios.get(n, {})
         if n in ('offset', 'offset_h', 'offset_v'):
-            vh, vv = draw_offset(B, H, W, 1, 0 if n == 'offset_v' else 1, 0 if n == 'offset_h' else 1, generator)
+            vh, vv = draw_offset(B, H, W, kw.get('ratio', 1), kw.get('ratio_h', 0 if n == 'offset_v' else 1),
+                                 kw.get('ratio_v', 0 if n == 'offset_h' else 1), generator)
             p[:, 2], p[:, 1] = vh.int(), vv.int()
         elif n == 'translation':
-            sh, sw = draw_translation(B, H, W, generator=generator)
+            sh, sw = draw_translation(B, H, W, kw.get('ratio', 0.125), generator=generator)
             p[:, 3], p[:, 4] = sh.int(), sw.int()
         elif n == 'cutout':
-            for k, v in zip((5, 6, 7, 8), draw_cutout(B, H, W, generator=generator)):
+            for k, v in zip((5, 6, 7, 8), draw_cutout(B, H, W, kw.get('ratio', 0.5), generator=generator)):
                 p[:, k] = v.int()
     return augment_spatial(x, p)
 

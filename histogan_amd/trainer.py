@@ -46,6 +46,7 @@ G_OVERLAP = os.environ.get('HG_G_OVERLAP', '1') != '0'   # G-phase generator for
 #   2:    the static-input step WITHOUT capture (A/B of the replay: identical parameter checksums, tools/graph_probe.py)
 GRAPH_MODE = os.environ.get('HG_GRAPH', 'auto')
 GRAPH_AUTO_RATIO = float(os.environ.get('HG_GRAPH_AUTO_RATIO', '0.6'))
+GRAPH_GP = os.environ.get('HG_GRAPH_GP', '1') != '0'      # gradient-penalty steps replay from their own graph too
 
 
 class NanException(Exception):
@@ -361,7 +362,9 @@ class Trainer():
         Captured: the plain step of a single-process run without DiffAugment / feature quantisation / gradient
         accumulation (those draw host-side random tables, keep batch-dependent buffers or change the launch sequence).
         HG_GRAPH=0 switches it off."""
-        if self.graph_mode == '0' or apply_gradient_penalty or apply_path_penalty or ddp.is_dist():
+        if self.graph_mode == '0' or apply_path_penalty or ddp.is_dist():    # (path-length steps branch on the host: eager)
+            return False
+        if apply_gradient_penalty and not GRAPH_GP:
             return False
         if self.gradient_accumulate_every != 1 or self.aug_prob > 0.0 or self.rng.mode != 'device':
             return False
@@ -412,7 +415,9 @@ class Trainer():
         first = (torch.arange(layers, device=self.device) < tt_dev).view(1, layers, 1)
         return torch.where(first, w1[:, None, :], w2[:, None, :])
 
-    def _graphed_step(self, alpha):
+    def _graphed_step(self, alpha, gp=False):
+        """One step from a captured graph; gp: the gradient-penalty variant (its own graph, same memory pool -- the two
+        are never in flight together)."""
         GAN = self.GAN
         gs = self._graph_inputs()
         self._fill_graph_inputs(gs)
@@ -421,19 +426,22 @@ class Trainer():
         if self.graph_mode == '2':             # HG_GRAPH=2: the static-input step WITHOUT capture (A/B of the replay)
             for o in (GAN.D_opt, GAN.G_opt):
                 o.graph_mode = True
-            stats = self._device_step(alpha, False, False, gs)
+            stats = self._device_step(alpha, gp, False, gs)
             for o in (GAN.D_opt, GAN.G_opt):
                 o.graph_mode = False
             return stats
-        if getattr(self, '_graph', None) is None:
+        graphs = self.__dict__.setdefault('_graphs', {})
+        if gp not in graphs:
             weights_changed()                  # every packed operand the step reads must be produced INSIDE the graph
             for o in (GAN.D_opt, GAN.G_opt):
                 o.graph_mode = True
             graph = torch.cuda.CUDAGraph()
             try:
                 torch.cuda.synchronize()
-                with torch.cuda.graph(graph):
-                    stats = self._device_step(alpha, False, False, gs)
+                pool = getattr(self, '_graph_pool', None)
+                with torch.cuda.graph(graph, pool=pool):
+                    stats = self._device_step(alpha, gp, False, gs)
+                self._graph_pool = graph.pool()
             except Exception as e:             # capture refused (driver / library limitation): stay eager
                 for o in (GAN.D_opt, GAN.G_opt):
                     o.graph_mode = False
@@ -442,13 +450,15 @@ class Trainer():
                 torch.cuda.synchronize()
                 print(f'hipGraph capture of the train step failed ({type(e).__name__}: {e}); running eagerly')
                 weights_changed()
-                return self._device_step(alpha, False, False, None)
+                return self._device_step(alpha, gp, False, None)
             for o in (GAN.D_opt, GAN.G_opt):
                 o.graph_mode = False
-            self._graph, self._graph_stats = graph, stats
-        self._graph.replay()
+            graphs[gp] = (graph, stats)
+            self._graph = graph
+        graph, stats = graphs[gp]
+        graph.replay()
         weights_changed()                      # eager steps in between must not trust operands packed by the graph
-        return self._graph_stats
+        return stats
 
     def _device_step(self, alpha, apply_gradient_penalty, apply_path_penalty, gs=None):
         """All device work of one optimisation step (reference :853-989), no host synchronisation.  gs: static input
@@ -514,6 +524,8 @@ class Trainer():
             else:
                 get_latents_fn = None
                 image_batch, hist_batch = gs['images'], gs['hist_d']
+                if apply_gradient_penalty:
+                    image_batch = image_batch.detach().requires_grad_(True)     # same storage: d D(real) / d images
             with torch.no_grad():   # the reference detaches this output; no graph is needed
                 if gs is None:
                     w_styles, h_w_space = self._w_and_hw(style, hist_batch)
@@ -615,15 +627,16 @@ class Trainer():
         t_host0 = perf_counter()
         apply_gradient_penalty = self.steps % 4 == 0
         apply_path_penalty = self.steps % 32 == 0
-        if self._graph_eligible(apply_gradient_penalty, apply_path_penalty):
-            stats = self._graphed_step(alpha)
+        graphed = self._graph_eligible(apply_gradient_penalty, apply_path_penalty)
+        if graphed:
+            stats = self._graphed_step(alpha, apply_gradient_penalty)
         else:
             stats = self._device_step(alpha, apply_gradient_penalty, apply_path_penalty, None)
 
         # ---- one read-back for everything the host needs (reference: >= 7 syncs)
         # host time spent enqueueing this step (everything before the one blocking read-back); graphed: the replay call
         self.host_enqueue_ms = (perf_counter() - t_host0) * 1e3
-        self.last_step_graphed = getattr(self, '_graph', None) is not None and not (apply_gradient_penalty or apply_path_penalty)
+        self.last_step_graphed = bool(graphed) and self.graph_mode != '2' and not getattr(self, '_graph_failed', False)
         self._t_host0 = t_host0
         if ddp.is_dist():
             nan_flag = torch.isnan(stats[:4]).any().double().reshape(1)

@@ -88,3 +88,35 @@ def test_train_steps_with_augmentation(gpu_device, tmp_path):
         tr.train(alpha=2)
     assert tr.GAN.D_aug is not None and np.isfinite(tr.d_loss) and np.isfinite(tr.g_loss) and np.isfinite(tr.last_gp_loss)
     assert any(k.startswith('D_aug.D.') for k in tr.GAN.state_dict())      # the reference's checkpoint layout
+
+
+def test_non_default_ratios(gpu_device):
+    """utils.diff_augment with the ratio arguments of the reference's functions (diff_augment.py:33-97): the draws obey
+    the ratio's bounds and the result is the gather the drawn parameters describe."""
+    from utils import diff_augment as U
+    x = torch.rand(6, 3, 20, 24, device=gpu_device)
+    torch.manual_seed(1)
+    y = U.rand_translation(x, ratio=0.25)                # shifts within +-5 rows / +-6 columns, zero fill
+    assert y.shape == x.shape
+    found = 0
+    for b in range(6):
+        ok = False
+        for sh in range(-5, 6):
+            for sw in range(-6, 7):
+                ref = torch.zeros_like(x[b])
+                ys0, ys1 = max(0, -sh), min(20, 20 - sh)
+                xs0, xs1 = max(0, -sw), min(24, 24 - sw)
+                ref[:, ys0:ys1, xs0:xs1] = x[b][:, ys0 + sh:ys1 + sh, xs0 + sw:xs1 + sw]
+                if torch.equal(ref, y[b]):
+                    ok = True
+        found += int(ok)
+    assert found == 6
+    z = U.rand_cutout(x, ratio=0.25)                     # a 5 x 6 hole (clipped at the border) of zeros per sample
+    for b in range(6):
+        hole = (z[b] == 0).all(dim=0)
+        assert (z[b][:, ~hole] == x[b][:, ~hole]).all()
+        rows, cols = hole.any(dim=1).sum().item(), hole.any(dim=0).sum().item()
+        assert 1 <= rows <= 5 and 1 <= cols <= 6
+    w = U.rand_offset(x, ratio=0.5, ratio_h=1, ratio_v=0)   # a roll along W only, |roll| <= int(H*0.5)
+    for b in range(6):
+        assert any(torch.equal(torch.roll(x[b], r, dims=2), w[b]) for r in range(-10, 11))

@@ -28,8 +28,8 @@ def _run(mode, steps, tmp_path):
 
 def test_graph_replay_equals_static_eager_step(gpu_device, tmp_path):
     a, ga = _run('2', 14, tmp_path)       # static inputs, no capture
-    b, gb = _run('1', 14, tmp_path)       # captured at step 6, replayed on every later plain step
-    assert ga == 0 and gb == 6 and not getattr(b, '_graph_failed', False)        # steps 6,7, 9,10,11, 13
+    b, gb = _run('1', 14, tmp_path)       # plain step captured at step 6, gradient-penalty step at step 8; replayed afterwards
+    assert ga == 0 and gb == 8 and not getattr(b, '_graph_failed', False)        # steps 6,7, 8 (GP), 9,10,11, 12 (GP), 13
     for name in ('_flat_g', '_flat_d'):
         assert torch.equal(getattr(a.GAN, name).data, getattr(b.GAN, name).data), name
     assert a.GAN.G_opt.step_count == b.GAN.G_opt.step_count == 14

@@ -19,15 +19,11 @@ def rand_contrast(x):
 
 
 def rand_translation(x, ratio=0.125):
-    if ratio != 0.125:
-        raise NotImplementedError('rand_translation: only the reference default ratio=0.125')
-    return _spatial_run(x, ['translation'])
+    return _spatial_run(x, ['translation'], ratios={'translation': dict(ratio=ratio)})
 
 
 def rand_offset(x, ratio=1, ratio_h=1, ratio_v=1):
-    if (ratio, ratio_h, ratio_v) not in ((1, 1, 1), (1, 1, 0), (1, 0, 1)):
-        raise NotImplementedError('rand_offset: only the ratios the reference uses')
-    return _spatial_run(x, ['offset' if ratio_h and ratio_v else 'offset_h' if ratio_h else 'offset_v'])
+    return _spatial_run(x, ['offset'], ratios={'offset': dict(ratio=ratio, ratio_h=ratio_h, ratio_v=ratio_v)})
 
 
 def rand_offset_h(x, ratio=1):
@@ -39,9 +35,7 @@ def rand_offset_v(x, ratio=1):
 
 
 def rand_cutout(x, ratio=0.5):
-    if ratio != 0.5:
-        raise NotImplementedError('rand_cutout: only the reference default ratio=0.5')
-    return _spatial_run(x, ['cutout'])
+    return _spatial_run(x, ['cutout'], ratios={'cutout': dict(ratio=ratio)})
 
 
 AUGMENT_FNS = {
