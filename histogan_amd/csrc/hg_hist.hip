@@ -3,7 +3,10 @@
 // Replaces the ~80-launch-per-image aten chain of the reference
 // (histogram_classes/RGBuvHistBlock.py:75-228) and its autograd replay by
 //   forward : k_hist_fwd  (MFMA split-K over pixels)  -> k_hist_reduce -> k_hist_normalize
-//   backward: k_hist_bwd_prep -> k_hist_bwd (MFMA, recompute-not-store) [-> resize adjoint]
+//   backward: k_hist_bwd (MFMA, mirrored-bin merge: symmetric boundary, h <= 64) or k_hist_bwd_planes (MFMA, one plane
+//             at a time: any boundary, h <= 128, one-plane projections) [-> resize adjoint]; k_hist_bwd_generic beyond
+//   method = thresholding: k_thr_fwd_lean -> k_hist_finish / k_thr_bwd_lean (true scatter-add; HBM / VALU bound);
+//   method = RBF with a narrow kernel: k_hist_rbf_fwd / k_hist_rbf_bwd (truncated scatter / gather)
 //
 // Maths:  with L_c = log(x_c + 1e-6), a = L_R-L_G, b = L_R-L_B, c = L_G-L_B,
 // Iy = sqrt(R^2+G^2+B^2+1e-6), k(.) the soft-bin kernel and bins b_i = linspace(lo,hi,h):
