@@ -268,9 +268,10 @@ __global__ __launch_bounds__(256) void k_dnl_bwd(const float *__restrict__ gout,
 }
 
 // gd / gwn_part / gbn_part [plane] = sum over chunks of the three partial arrays (fixed order)
+// ddiv != NULL (conv was recovered from out: the first sum is of m * conv * d): gd = that sum / d
 __global__ __launch_bounds__(256) void k_dnl_bwd_finish(const float *__restrict__ part, float *__restrict__ gd,
-                                                        float *__restrict__ gw, float *__restrict__ gb, int planes,
-                                                        int chunks) {
+                                                        float *__restrict__ gw, float *__restrict__ gb,
+                                                        const float *__restrict__ ddiv, int planes, int chunks) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= planes) return;
   float v0 = 0.f, v1 = 0.f, v2 = 0.f;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void k_dnl_bwd_finish(const float *__restrict_
     v1 += part[(size_t)planes * chunks + (size_t)p * chunks + c];
     v2 += part[2 * (size_t)planes * chunks + (size_t)p * chunks + c];
   }
-  if (gd) gd[p] = v0;
+  if (gd) gd[p] = ddiv ? v0 / ddiv[p] : v0;
   gw[p] = v1;
   gb[p] = v2;
 }
@@ -438,8 +439,8 @@ int hg_demod_noise_lrelu_bwd(const float *gout, const float *out, const float *c
   hipLaunchKernelGGL(k_dnl_bwd, dim3(chunks, planes), dim3(256), 0, st, gout, out, conv, d, nzt, wn, bn, gconv, part, O, H,
                      S);
   HG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_dnl_bwd_finish, dim3((planes + 255) / 256), dim3(256), 0, st, part, gd, gwn_part, gbn_part, planes,
-                     chunks);
+  hipLaunchKernelGGL(k_dnl_bwd_finish, dim3((planes + 255) / 256), dim3(256), 0, st, part, gd, gwn_part, gbn_part,
+                     (!conv && d) ? d : nullptr, planes, chunks);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }

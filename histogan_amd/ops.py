@@ -11,6 +11,9 @@ import torch
 from ._lib import check, lib, on_device, raw_stream
 
 
+KEEP_CONV = __import__('os').environ.get('HG_DNL_KEEP_CONV', '1') != '0'
+
+
 def _st(t):
     return raw_stream(t.device)
 
@@ -98,27 +101,34 @@ class _DemodNoiseLrelu(torch.autograd.Function):
             check(lib.hg_demod_noise_lrelu_fwd(conv.data_ptr(), None if d is None else d.data_ptr(), nzt.data_ptr(),
                                                wn.data_ptr(), bn.data_ptr(), out.data_ptr(), B, O, H, S, _st(conv)),
                   'hg_demod_noise_lrelu_fwd')
-        ctx.save_for_backward(conv, d, nzt, out)
-        ctx.wn_shape = None
+        # HG_DNL_KEEP_CONV=0: the convolution output is not kept for the backward; conv*d is recovered from `out` there
+        # (pre = out > 0 ? out : 5 out, minus the noise term) -- one tensor less per stage and one read less in k_dnl_bwd.
+        # Measured at C3: 54.7 vs 54.5 ms per plain step (the kernel hides behind the side-stream weight gradients), so
+        # the stored operand (no recovery rounding) stays the default.
+        if KEEP_CONV:
+            ctx.save_for_backward(conv, d, nzt, out, wn, bn)
+        else:
+            ctx.save_for_backward(None, d, nzt, out, wn, bn)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        conv, d, nzt, out = ctx.saved_tensors
+        conv, d, nzt, out, wn, bn = ctx.saved_tensors
         g = _f32c(g.detach())
-        B, O, H, _ = conv.shape
+        B, O, H, _ = out.shape
         S = nzt.shape[-1]
-        with on_device(conv.device):
-            gconv = torch.empty_like(conv)
+        with on_device(out.device):
+            gconv = torch.empty_like(out)
             gd = None if d is None else torch.empty_like(d)
-            gw = torch.empty((B, O), dtype=torch.float32, device=conv.device)
-            gb = torch.empty((B, O), dtype=torch.float32, device=conv.device)
-            ws, n = _ws(conv, B, O, H, H)
-            check(lib.hg_demod_noise_lrelu_bwd(g.data_ptr(), out.data_ptr(), conv.data_ptr(),
-                                               None if d is None else d.data_ptr(), nzt.data_ptr(), None, None,
-                                               gconv.data_ptr(),
+            gw = torch.empty((B, O), dtype=torch.float32, device=out.device)
+            gb = torch.empty((B, O), dtype=torch.float32, device=out.device)
+            ws, n = _ws(out, B, O, H, H)
+            check(lib.hg_demod_noise_lrelu_bwd(g.data_ptr(), out.data_ptr(), None if conv is None else conv.data_ptr(),
+                                               None if d is None else d.data_ptr(), nzt.data_ptr(),
+                                               None if conv is not None else wn.data_ptr(),
+                                               None if conv is not None else bn.data_ptr(), gconv.data_ptr(),
                                                None if gd is None else gd.data_ptr(), gw.data_ptr(), gb.data_ptr(),
-                                               B, O, H, S, ws.data_ptr(), n, _st(conv)), 'hg_demod_noise_lrelu_bwd')
+                                               B, O, H, S, ws.data_ptr(), n, _st(out)), 'hg_demod_noise_lrelu_bwd')
         return gconv, gd, None, gw.sum(0).reshape(-1, 1), gb.sum(0)
 
 
@@ -206,8 +216,7 @@ class _ModConvStage(torch.autograd.Function):
                                                    gb_p.data_ptr(), B, N, Hi, S, ws.data_ptr(), n, _st(x)),
                       'hg_demod_noise_lrelu_bwd')
                 gwn, gbn = gw_p.sum(0).reshape(-1, 1), gb_p.sum(0)
-                if d is not None:
-                    gd = gdr / d
+                gd = gdr
             else:
                 if d is not None:
                     raise RuntimeError('modconv_stage: demodulation without activation is not implemented')

@@ -46,7 +46,8 @@ int hg_demod_noise_lrelu_fwd(const float *conv, const float *d, const float *nzt
 /* m = gout * (out > 0 ? 1 : 0.2):  gconv = m * d;  gd[b,o] = sum m*conv  (gd may be NULL when d is);
  * gwn_part[b,o] = sum m * nzt[b,i,j];  gbn_part[b,o] = sum m   (caller sums the parts over b).
  * conv may be NULL (the fused forward hg_modconv2d_fwd never stores it): then wn, bn (O) are needed, conv*d is
- * recovered from out, and gd[b,o] = sum m*conv*d  (the caller divides by d). */
+ * recovered from out (pre = out > 0 ? out : 5 out, minus the noise term) and the sum of m*conv*d is divided by d[b,o]
+ * before it is stored: gd has the same meaning either way. */
 int hg_demod_noise_lrelu_bwd(const float *gout, const float *out, const float *conv, const float *d,
                              const float *nzt, const float *wn, const float *bn, float *gconv, float *gd,
                              float *gwn_part, float *gbn_part, int32_t B, int32_t O, int32_t H, int32_t S,
