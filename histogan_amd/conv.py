@@ -29,7 +29,7 @@ B6_MIN_PIX = 4096
 
 
 def _use_b6(K, N, H, W, B, k, stride):
-    return PRECISION == 'b6' and k == 3 and stride == 1 and K >= 16 and B * H * W >= B6_MIN_PIX
+    return PRECISION in ('b6', 'b9') and k == 3 and stride == 1 and K >= 16 and B * H * W >= B6_MIN_PIX
 
 
 @contextlib.contextmanager
@@ -179,11 +179,13 @@ def pack_b6(w, mode):
     return cached(w, ('b6', mode), make)
 
 
-def conv_b6(x, wt, N, bias=None):
+def conv_b6(x, wt, N, bias=None, nprod=None):
+    """nprod: 6 (bf16x6) or 9 (bf16x9: exact products); default from HG_CONV_PRECISION."""
     B, K, H, W = x.shape
+    fn = lib.hg_conv2d_b9 if (nprod or (9 if PRECISION == 'b9' else 6)) == 9 else lib.hg_conv2d_b6
     with on_device(x.device):
         out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
-        check(lib.hg_conv2d_b6(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(bias), B, K, N, H, W, _st(x)), 'hg_conv2d_b6')
+        check(fn(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(bias), B, K, N, H, W, _st(x)), 'hg_conv2d_b6/b9')
     return out
 
 

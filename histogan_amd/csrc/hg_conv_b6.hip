@@ -51,7 +51,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &h, bf16x8 &m
   }
 }
 
-template <int WC, int WP, int TC, int TP>
+// NPROD = 6: the products down to 2^-16 (error 2-4e-6 against fp64 where the fp32 MFMA has 1-2e-6);
+// NPROD = 9: all nine -- the bf16 x bf16 partial products are exact in fp32 and sum to the exact fp32 product, so only
+// the ACCUMULATION differs from the fp32 MFMA's fma chain ("bf16x9", 9/16 of the fp32-MFMA time on the matrix pipe).
+template <int WC, int WP, int TC, int TP, int NPROD>
 __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv_b6(const B6Args a) {
   constexpr int NT = WC * WP * 64;
   constexpr int NB = WC * TC * 32, MB = WP * TP * 32;
@@ -169,6 +172,11 @@ __global__ __launch_bounds__(WC *WP * 64, 2) void k_conv_b6(const B6Args a) {
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
           f32x16 v = acc[i][j];
+          if constexpr (NPROD == 9) {                                                       // smallest terms first
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[i][2], bf[j][2], v, 0, 0, 0);   // l*l
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[i][1], bf[j][2], v, 0, 0, 0);   // m*l
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[i][2], bf[j][1], v, 0, 0, 0);   // l*m
+          }
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[i][0], bf[j][2], v, 0, 0, 0);   // h*l
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[i][2], bf[j][0], v, 0, 0, 0);   // l*h
           v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(acur[i][1], bf[j][1], v, 0, 0, 0);   // m*m
@@ -264,12 +272,12 @@ GeomB make_geom_b(int MB, int B, int H, int W) {
   return g;
 }
 
-template <int WC, int WP, int TC, int TP>
+template <int WC, int WP, int TC, int TP, int NPROD>
 int launch_b6(B6Args a, hipStream_t st) {
   constexpr int NB = WC * TC * 32, MB = WP * TP * 32, NT = WC * WP * 64;
   a.g = make_geom_b(MB, a.B, a.H, a.W);
   const size_t lds = (size_t)6 * a.g.HALO * 16;
-  auto kern = k_conv_b6<WC, WP, TC, TP>;
+  auto kern = k_conv_b6<WC, WP, TC, TP, NPROD>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -278,6 +286,25 @@ int launch_b6(B6Args a, hipStream_t st) {
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);
   HG_LAUNCH_CHECK();
   return HG_OK;
+}
+
+template <int NPROD>
+int conv2d_bx(const float *in, const void *wt, float *out, const float *bias, int32_t B, int32_t K, int32_t N,
+                     int32_t H, int32_t W, void *stream) {
+  if (!in || !wt || !out || B <= 0 || K <= 0 || N <= 0 || H <= 0 || W <= 0) return HG_EINVAL;
+  if ((long long)B * K * H * W >= 0x7fffffffLL || (long long)B * N * H * W >= 0x7fffffffLL) return HG_EUNSUPPORTED;
+  B6Args a;
+  a.in = in; a.wt = (const bf16x8 *)wt; a.out = out; a.bias = bias;
+  a.B = B; a.K = K; a.N = N; a.H = H; a.W = W;
+  a.KCH = round_upb(K, 16) / 16; a.Np = round_upb(N, 128);
+  hipStream_t st = (hipStream_t)stream;
+  const long long pix = (long long)B * H * W;
+  auto blocks = [&](int nb, int mb) { return ((N + nb - 1) / nb) * ((pix + mb - 1) / mb); };
+  const bool wide256 = W > 8 && H > 8, wide128 = W > 4 && H > 4;
+  if (N <= 32 && wide256) return launch_b6<1, 4, 1, 2, NPROD>(a, st);
+  if (N <= 64 && wide256 && blocks(64, 256) >= 384) return launch_b6<1, 4, 2, 2, NPROD>(a, st);
+  if (N > 64 && wide128 && blocks(128, 128) >= 256) return launch_b6<2, 2, 2, 2, NPROD>(a, st);
+  return launch_b6<2, 2, 1, 1, NPROD>(a, st);
 }
 
 }  // namespace
@@ -305,20 +332,12 @@ int hg_conv_b6_pack_weights(const float *w, void *wt, int32_t Co, int32_t Ci, in
 
 int hg_conv2d_b6(const float *in, const void *wt, float *out, const float *bias, int32_t B, int32_t K, int32_t N,
                  int32_t H, int32_t W, void *stream) {
-  if (!in || !wt || !out || B <= 0 || K <= 0 || N <= 0 || H <= 0 || W <= 0) return HG_EINVAL;
-  if ((long long)B * K * H * W >= 0x7fffffffLL || (long long)B * N * H * W >= 0x7fffffffLL) return HG_EUNSUPPORTED;
-  B6Args a;
-  a.in = in; a.wt = (const bf16x8 *)wt; a.out = out; a.bias = bias;
-  a.B = B; a.K = K; a.N = N; a.H = H; a.W = W;
-  a.KCH = round_upb(K, 16) / 16; a.Np = round_upb(N, 128);
-  hipStream_t st = (hipStream_t)stream;
-  const long long pix = (long long)B * H * W;
-  auto blocks = [&](int nb, int mb) { return ((N + nb - 1) / nb) * ((pix + mb - 1) / mb); };
-  const bool wide256 = W > 8 && H > 8, wide128 = W > 4 && H > 4;
-  if (N <= 32 && wide256) return launch_b6<1, 4, 1, 2>(a, st);
-  if (N <= 64 && wide256 && blocks(64, 256) >= 384) return launch_b6<1, 4, 2, 2>(a, st);
-  if (N > 64 && wide128 && blocks(128, 128) >= 256) return launch_b6<2, 2, 2, 2>(a, st);
-  return launch_b6<2, 2, 1, 1>(a, st);
+  return conv2d_bx<6>(in, wt, out, bias, B, K, N, H, W, stream);
+}
+
+int hg_conv2d_b9(const float *in, const void *wt, float *out, const float *bias, int32_t B, int32_t K, int32_t N,
+                 int32_t H, int32_t W, void *stream) {
+  return conv2d_bx<9>(in, wt, out, bias, B, K, N, H, W, stream);
 }
 
 }  // extern "C"

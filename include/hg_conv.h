@@ -90,6 +90,11 @@ size_t hg_conv_b6_packed_bytes(int32_t Co, int32_t Ci, int32_t mode);
 int hg_conv_b6_pack_weights(const float *w, void *wt, int32_t Co, int32_t Ci, int32_t mode, void *stream);
 int hg_conv2d_b6(const float *in, const void *wt, float *out, const float *bias, int32_t B, int32_t K, int32_t N,
                  int32_t H, int32_t W, void *stream);
+/* The same with all nine bf16 partial products ("bf16x9"): every partial product is exact in fp32 and they sum to the
+ * exact fp32 product, so only the accumulation order differs from the fp32 MFMA's fma chain; 9/16 of its matrix-pipe time.
+ * Same packed operand as hg_conv2d_b6. */
+int hg_conv2d_b9(const float *in, const void *wt, float *out, const float *bias, int32_t B, int32_t K, int32_t N,
+                 int32_t H, int32_t W, void *stream);
 
 #ifdef __cplusplus
 }
