@@ -303,6 +303,10 @@ class Trainer():
         self.loader_evaluate = None
 
     def init_GAN(self):
+        # a captured train-step graph points into the previous model's buffers: drop it (load() -> load_config() rebuilds
+        # the GAN, e.g. on NaN recovery); the next eligible step captures again
+        for k in ('_graphs', '_graph', '_graph_pool', '_gs', '_gs_first'):
+            self.__dict__.pop(k, None)
         args, kwargs = self.GAN_params
         self.GAN = HistoGAN(lr=self.lr, image_size=self.image_size, network_capacity=self.network_capacity,
                             transparent=self.transparent, fq_layers=self.fq_layers,

