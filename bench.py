@@ -425,12 +425,25 @@ def main():
     for _ in range(args.warmup):
         step()
     tr = getattr(step, 'trainer', None)
+    if tr is not None and hasattr(tr, '_graph_eligible'):
+        # HG_GRAPH=auto decides from its first eager plain steps whether plain / gradient-penalty steps replay from
+        # captured hipGraphs; a capture is a one-time ~0.15 s.  Keep both out of the timed window: untimed settle steps
+        # until the decision is made and, if it is "graph", both graphs exist (at most 16 steps).
+        for _ in range(16):
+            decided = tr.graph_mode != 'auto' or getattr(tr, '_graph_auto', None) is not None
+            use = tr.graph_mode == '1' or getattr(tr, '_graph_auto', False)
+            have = set(getattr(tr, '_graphs', {}).keys())
+            if decided and (not use or getattr(tr, '_graph_failed', False) or have >= {False, True}):
+                break
+            step()
     if tr is not None:
         # Pin the schedule phase: the timed window starts on a step with steps % 32 == 0, so K timed steps always hold
         # ceil(K/4) gradient-penalty steps and ceil(K/32) path-length steps (the reference's mix, histoGAN.py:882-883),
         # whatever --warmup was.  (With K < 32 the one path-length step weighs more than its 1/32 share: the
         # `schedule_mix` entry below re-weights the measured per-kind means to the 32-step period.)
-        tr.steps = 32 * ((tr.steps + 31) // 32)
+        # Windows that are not a multiple of 32 hold round(K / 32) path-length steps (K = 20: one; K = 8: none, the
+        # window then starts one step later) -- the composition closest to the 32-step period.
+        tr.steps = 32 * ((tr.steps + 31) // 32) + (0 if (args.steps % 32 == 0 or round(args.steps / 32.0) >= 1) else 1)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

@@ -380,7 +380,7 @@ class Trainer():
             use = getattr(self, '_graph_auto', None)
             if use is None:
                 r = sorted(getattr(self, '_host_ratio', []))
-                if len(r) < 3:
+                if len(r) < 2:
                     return False
                 use = self._graph_auto = r[len(r) // 2] > GRAPH_AUTO_RATIO
             return use
