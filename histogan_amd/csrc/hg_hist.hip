@@ -2,7 +2,7 @@
 //
 // Replaces the ~80-launch-per-image aten chain of the reference
 // (histogram_classes/RGBuvHistBlock.py:75-228) and its autograd replay by
-//   forward : k_hist_fwd  (MFMA split-K over pixels)  -> k_hist_reduce -> k_hist_normalize
+//   forward : k_hist_fwd  (MFMA split-K over pixels)  -> k_hist_finish (slab sum + normalisation)
 //   backward: k_hist_bwd (MFMA, mirrored-bin merge: symmetric boundary, h <= 64) or k_hist_bwd_planes (MFMA, one plane
 //             at a time: any boundary, h <= 128, one-plane projections) [-> resize adjoint]; k_hist_bwd_generic beyond
 //   method = thresholding: k_thr_fwd_lean -> k_hist_finish / k_thr_bwd_lean (true scatter-add; HBM / VALU bound);
@@ -213,7 +213,8 @@ __device__ __forceinline__ void lds_wave_sync() {
 // LDS in fixed order and written as one slab  slabs[b][s][p][h][h]  (real bin order, flips undone).
 template <int T, int METHOD, bool SYM, bool DIAG, bool GREEN>
 __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const float *__restrict__ x,
-                                                     float *__restrict__ slabs, const int chunk) {
+                                                     float *__restrict__ slabs, double *__restrict__ slab_tot,
+                                                     const int chunk) {
   constexpr int BLK = 32 * T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4 *stage = reinterpret_cast<float4 *>(smem);            // [4 waves][64 pixels]
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
   // slab write: slabs[((b*S+s)*Pn + po)*h*h + oi*h + oj], undoing the index flips of planes 1, 2
   const int h = P.h, Pn = P.P;
   float *slab = slabs + ((long long)(b * S + s) * Pn) * h * h;
+  float tsum = 0.f;
   for (int e = threadIdx.x; e < 3 * BLK * BLK; e += 256) {
     const int p = e / (BLK * BLK), rem = e - p * BLK * BLK;
     const int il = rem / BLK, jl = rem - il * BLK;
@@ -355,44 +357,14 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
     const int oi = (p == 0) ? I : h - 1 - I;
     const int oj = (p == 2) ? h - 1 - J : J;
     const int po = green ? 0 : p;
-    slab[((long long)po * h + oi) * h + oj] = red[e];
+    const float v = red[e];
+    slab[((long long)po * h + oi) * h + oj] = v;
+    tsum += v;
   }
-}
-
-// Sum the S slabs of each image (fixed order), write the raw histogram and one partial total per block.
-__global__ __launch_bounds__(256) void k_hist_reduce(const float *__restrict__ slabs, float *__restrict__ raw,
-                                                     float *__restrict__ partials, int S, int n_per_img) {
-  __shared__ float sm4[4];
-  const int b = blockIdx.y;
-  const float *src = slabs + (long long)b * S * n_per_img;
-  float tot = 0.f;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int e = blockIdx.x * 1024 + k * 256 + threadIdx.x;
-    if (e < n_per_img) {
-      float v = 0.f;
-      for (int s = 0; s < S; ++s) v += src[(long long)s * n_per_img + e];
-      raw[(long long)b * n_per_img + e] = v;
-      tot += v;
-    }
-  }
-  tot = hg_block_sum_256(tot, sm4);
-  if (threadIdx.x == 0) partials[b * gridDim.x + blockIdx.x] = tot;
-}
-
-// Stage 4 (normalise), RGBuvHistBlock.py:224-228: hist / (sum + 1e-6); in place.
-__global__ __launch_bounds__(256) void k_hist_normalize(float *__restrict__ hist, const float *__restrict__ partials,
-                                                        float *__restrict__ sum_out, int n_per_img) {
-  const int b = blockIdx.y, np = gridDim.x;
-  float tot = 0.f;
-  for (int k = 0; k < np; ++k) tot += partials[b * np + k];
-  const float den = tot + kEps;
-  if (blockIdx.x == 0 && threadIdx.x == 0) sum_out[b] = den;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int e = blockIdx.x * 1024 + k * 256 + threadIdx.x;
-    if (e < n_per_img) hist[(long long)b * n_per_img + e] /= den;
-  }
+  // this workgroup's share of the image total (fixed summation order): k_hist_finish needs no pass to find the normaliser
+  __syncthreads();
+  tsum = hg_block_sum_256(tsum, reinterpret_cast<float *>(smem));
+  if (threadIdx.x == 0) slab_tot[((long long)b * S + s) * gridDim.y + blockIdx.y] = (double)tsum;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -924,7 +896,7 @@ __global__ __launch_bounds__(64) void k_hist_bwd_generic(const DevParams P, cons
 // product of the smooth kernels.  One workgroup takes a pixel range of one image and, plane after plane, bins it
 // into an h x h LDS grid with 64-bit FIXED-POINT atomics (Iy * 2^32): integer sums are order-independent, so the
 // result is deterministic (and more accurate than an fp32 running sum); the grid is flushed as a float slab in the
-// layout of k_hist_fwd (k_hist_reduce / k_hist_normalize finish as usual).  Pixels are re-projected per plane
+// layout of k_hist_fwd (k_hist_finish sums and normalises).  Pixels are re-projected per plane
 // (their second and third read hit L2).
 constexpr double kThrScale = 4294967296.0;   // 2^32
 
@@ -983,22 +955,22 @@ __device__ __forceinline__ unsigned long long block_sum_u64(unsigned long long v
   return t;
 }
 
-// Scatter paths: slab sum + normalisation in ONE launch (k_hist_reduce + k_hist_normalize of the dense path).  The
-// scatter kernels leave the exact total of every slab (integer sum of its fixed-point grid) in slab_tot[b][s], so the
-// normaliser of RGBuvHistBlock.py:224-228 needs no second pass over the histogram.
+// Slab sum + normalisation (stage 4, RGBuvHistBlock.py:224-228: hist / (sum + 1e-6)) in ONE launch.  The producing
+// kernels leave their share of the image total in slab_tot (scatter paths: the exact integer sum of each fixed-point
+// grid; k_hist_fwd: a fixed-order block sum), so the normaliser needs no pass of its own over the histogram.
 __global__ __launch_bounds__(256) void k_hist_finish(const float *__restrict__ slabs, const double *__restrict__ slab_tot,
                                                      float *__restrict__ hist, float *__restrict__ sum_out, int S,
-                                                     int n_per_img) {
+                                                     int ntot, int n_per_img) {
   __shared__ double st[256];
   const int b = blockIdx.y;
-  // the slab totals are fetched by S threads at once (a serial loop would pay S memory latencies) and summed in slab
-  // order by everyone
-  const int Sl = S < 256 ? S : 256;
-  if ((int)threadIdx.x < Sl) st[threadIdx.x] = slab_tot[b * S + threadIdx.x];
+  // the ntot partial totals of the image (one per slab, times the bin blocks of the dense path) are fetched by ntot
+  // threads at once (a serial loop would pay ntot memory latencies) and summed in order by everyone
+  const int Sl = ntot < 256 ? ntot : 256;
+  if ((int)threadIdx.x < Sl) st[threadIdx.x] = slab_tot[(long long)b * ntot + threadIdx.x];
   __syncthreads();
   double tot = 0.0;
   for (int s = 0; s < Sl; ++s) tot += st[s];
-  for (int s = 256; s < S; ++s) tot += slab_tot[b * S + s];       // more slabs than threads: never at these sizes
+  for (int s = 256; s < ntot; ++s) tot += slab_tot[(long long)b * ntot + s];   // more totals than threads: never at these sizes
   const float den = (float)tot + kEps;
   if (blockIdx.x == 0 && threadIdx.x == 0) sum_out[b] = den;
   const float *src = slabs + (long long)b * S * n_per_img;
@@ -1798,8 +1770,8 @@ Plan make_plan(const hg_hist_params *p) {
   pl.nparts = (int)((n_per_img + 1023) / 1024);
   pl.slab_bytes = (size_t)p->B * S * n_per_img * sizeof(float);
   pl.part_bytes = ((size_t)p->B * pl.nparts * sizeof(float) + 255) / 256 * 256;
-  if (sparse_path(p))   // slab_tot[B][S] doubles (k_hist_finish) instead of the per-block float partials
-    pl.part_bytes = ((size_t)p->B * S * sizeof(double) + 255) / 256 * 256;
+  // slab_tot[B][S (x bin blocks)] doubles for k_hist_finish
+  pl.part_bytes = ((size_t)p->B * S * pl.nbd * pl.nbd * sizeof(double) + 255) / 256 * 256;
   // backward: 1 workgroup per CU, rounds of 32 pixels per wave
   const long long rounds_total = (npix + 31) / 32;
   long long targetb = 512;
@@ -1850,29 +1822,32 @@ DevParams make_dev(const hg_hist_params *p) {
 }
 
 template <int T, int METHOD, bool GREEN>
-int launch_fwd_tmg(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, hipStream_t st) {
+int launch_fwd_tmg(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, double *slab_tot,
+                   hipStream_t st) {
   const dim3 grid(pl.S_fwd, pl.nbd * pl.nbd, d.B), block(256);
   const size_t lds = 4 * 64 * 16 + (size_t)3 * pl.BLK * pl.BLK * sizeof(float);
   const bool diag = pl.nbd == 1;
-  if (sym && diag) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, true, GREEN>), grid, block, lds, st, d, x, slabs, pl.chunk);
-  else if (sym) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, false, GREEN>), grid, block, lds, st, d, x, slabs, pl.chunk);
-  else hipLaunchKernelGGL((k_hist_fwd<T, METHOD, false, false, GREEN>), grid, block, lds, st, d, x, slabs, pl.chunk);
+  if (sym && diag) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, true, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
+  else if (sym) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, false, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
+  else hipLaunchKernelGGL((k_hist_fwd<T, METHOD, false, false, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
 
 template <int T, int METHOD>
-int launch_fwd_tm(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, hipStream_t st) {
-  return d.green ? launch_fwd_tmg<T, METHOD, true>(d, pl, sym, x, slabs, st)
-                 : launch_fwd_tmg<T, METHOD, false>(d, pl, sym, x, slabs, st);
+int launch_fwd_tm(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, double *slab_tot,
+                  hipStream_t st) {
+  return d.green ? launch_fwd_tmg<T, METHOD, true>(d, pl, sym, x, slabs, slab_tot, st)
+                 : launch_fwd_tmg<T, METHOD, false>(d, pl, sym, x, slabs, slab_tot, st);
 }
 
 template <int T>
-int launch_fwd_t(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, hipStream_t st) {
+int launch_fwd_t(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, double *slab_tot,
+                 hipStream_t st) {
   switch (d.method) {
-    case HG_METHOD_THRESHOLDING: return launch_fwd_tm<T, HG_METHOD_THRESHOLDING>(d, pl, sym, x, slabs, st);
-    case HG_METHOD_RBF: return launch_fwd_tm<T, HG_METHOD_RBF>(d, pl, sym, x, slabs, st);
-    default: return launch_fwd_tm<T, HG_METHOD_INVERSE_QUADRATIC>(d, pl, sym, x, slabs, st);
+    case HG_METHOD_THRESHOLDING: return launch_fwd_tm<T, HG_METHOD_THRESHOLDING>(d, pl, sym, x, slabs, slab_tot, st);
+    case HG_METHOD_RBF: return launch_fwd_tm<T, HG_METHOD_RBF>(d, pl, sym, x, slabs, slab_tot, st);
+    default: return launch_fwd_tm<T, HG_METHOD_INVERSE_QUADRATIC>(d, pl, sym, x, slabs, slab_tot, st);
   }
 }
 
@@ -1974,7 +1949,6 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
   if (workspace_bytes < pl.part_bytes + pl.slab_bytes) return HG_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const DevParams d = make_dev(p);
-  float *partials = (float *)workspace;
   float *slabs = (float *)((char *)workspace + pl.part_bytes);
   const bool sym = (p->lo == -p->hi);
   if (sparse_path(p)) {
@@ -2012,17 +1986,17 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
     HG_LAUNCH_CHECK();
     if (!R && thr_lean(p) && pl.S_fwd == 1) return HG_OK;          // normalised in the scatter kernel
     hipLaunchKernelGGL(k_hist_finish, dim3(pl.nparts, d.B), dim3(256), 0, st, slabs, slab_tot, hist_out, sum_out,
-                       pl.S_fwd, d.P * d.h * d.h);
+                       pl.S_fwd, pl.S_fwd, d.P * d.h * d.h);
     HG_LAUNCH_CHECK();
     return HG_OK;
   } else {
-    int r = (pl.T == 1) ? launch_fwd_t<1>(d, pl, sym, x, slabs, st) : launch_fwd_t<2>(d, pl, sym, x, slabs, st);
+    double *slab_tot = (double *)workspace;
+    int r = (pl.T == 1) ? launch_fwd_t<1>(d, pl, sym, x, slabs, slab_tot, st) : launch_fwd_t<2>(d, pl, sym, x, slabs, slab_tot, st);
     if (r) return r;
   }
-  const int n_per_img = d.P * d.h * d.h;
-  hipLaunchKernelGGL(k_hist_reduce, dim3(pl.nparts, d.B), dim3(256), 0, st, slabs, hist_out, partials, pl.S_fwd, n_per_img);
-  HG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_hist_normalize, dim3(pl.nparts, d.B), dim3(256), 0, st, hist_out, partials, sum_out, n_per_img);
+  // slab sum + normalisation in one launch (the MFMA kernel left every workgroup's share of the image total)
+  hipLaunchKernelGGL(k_hist_finish, dim3(pl.nparts, d.B), dim3(256), 0, st, slabs, (const double *)workspace, hist_out,
+                     sum_out, pl.S_fwd, pl.S_fwd * pl.nbd * pl.nbd, d.P * d.h * d.h);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
