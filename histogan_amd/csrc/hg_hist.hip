@@ -38,6 +38,9 @@
 #ifndef HG_FWD_VALU_PER_MFMA
 #define HG_FWD_VALU_PER_MFMA 4
 #endif
+#ifndef HG_FWD_PACKED
+#define HG_FWD_PACKED 1   // packed-fp32 (v_pk_*) operand generation in k_hist_fwd
+#endif
 #ifndef HG_FWD_MFMA_GROUP
 #define HG_FWD_MFMA_GROUP 12  // k_hist_fwd at configs[1]: groups of 1: 505 us, 3: 498, 6: 473, 12: 465
 #endif
@@ -252,7 +255,36 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
   const int end = (int)min((long long)P.npix, start + chunk);
   constexpr bool green = GREEN;
 
+  // Packed-fp32 operand generation (inverse-quadratic, two tiles per side): the two tiles' evaluations of one variable are
+  // one v_pk_fma / v_pk_add / v_pk_fma (+ two v_rcp) instead of two of each -- the same IEEE operations lane for lane,
+  // so bit-identical values; 17 VALU instructions per K step instead of 28.  (VALU work is what the fp32 MFMA cannot
+  // hide on gfx950.)
+  [[maybe_unused]] f32x2 chiA, cloA, chiAm, cloAm, chiB, cloB, chiBm, cloBm;
+  if constexpr (T == 2) {
+    chiA = f32x2{cA[0].chi, cA[1].chi}; cloA = f32x2{cA[0].clo, cA[1].clo};
+    chiAm = f32x2{cAm[0].chi, cAm[1].chi}; cloAm = f32x2{cAm[0].clo, cAm[1].clo};
+    chiB = f32x2{cB[0].chi, cB[1].chi}; cloB = f32x2{cB[0].clo, cB[1].clo};
+    chiBm = f32x2{cBm[0].chi, cBm[1].chi}; cloBm = f32x2{cBm[0].clo, cBm[1].clo};
+  }
+  auto iq2 = [&](float u, const f32x2 &chi, const f32x2 &clo) __attribute__((always_inline)) -> f32x2 {
+    const f32x2 uu = {u, u}, is = {P.inv_sigma, P.inv_sigma}, one = {1.f, 1.f};
+    const f32x2 t = __builtin_elementwise_fma(uu, is, chi) + clo;
+    const f32x2 den = __builtin_elementwise_fma(t, t, one);
+    return f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  };
   auto make_ops = [&](const float4 &q, Ops<T> &o) {
+    if constexpr (T == 2 && METHOD == HG_METHOD_INVERSE_QUADRATIC && HG_FWD_PACKED) {
+      const f32x2 w2 = {q.w, q.w};
+      const f32x2 ka = iq2(q.x, chiA, cloA), kbA = iq2(q.y, chiAm, cloAm);
+      const f32x2 a0 = w2 * ka, a2 = w2 * kbA;
+      const f32x2 a1 = SYM ? a0 : w2 * iq2(q.x, chiAm, cloAm);
+      const f32x2 b0 = (SYM && DIAG) ? kbA : iq2(q.y, chiB, cloB);
+      const f32x2 b1 = iq2(q.z, chiB, cloB);
+      const f32x2 b2 = SYM ? b1 : iq2(q.z, chiBm, cloBm);
+      o.A0[0] = a0.x; o.A0[1] = a0.y; o.A1[0] = a1.x; o.A1[1] = a1.y; o.A2[0] = a2.x; o.A2[1] = a2.y;
+      o.B0[0] = b0.x; o.B0[1] = b0.y; o.B1[0] = b1.x; o.B1[1] = b1.y; o.B2[0] = b2.x; o.B2[1] = b2.y;
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t) {
       const float ka = kern_eval<METHOD>(P, q.x, cA[t]);
@@ -282,25 +314,21 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
     if (base + 64 + lane < end) sample_rgb(P, xb, base + 64 + lane, r_, g_, b_);
     lds_wave_sync();
     const int steps = (min(64, end - base) + 1) >> 1;
-    // Software-pipelined K loop: the operands of step m+1 (VALU: 3..6 kernel vectors) are generated
-    // while the 3*T*T MFMAs of step m (64 cycles each) occupy the matrix pipe; the sched_group
-    // barriers ask for a 1 MFMA : 4 VALU interleave so a single wave keeps the pipe fed.
-    Ops<T> cur;
-    make_ops(stage[wave * 64 + half], cur);
-    float4 q1 = stage[wave * 64 + 2 * min(1, steps - 1) + half];
-    for (int m = 0; m < steps; ++m) {
-      // LDS read two steps ahead: its latency is covered by a whole step of MFMAs even when the two
-      // waves of a SIMD run phase-locked (the matrix-pipe arbiter interleaves their MFMAs 1:1).
-      float4 q2 = stage[wave * 64 + 2 * min(m + 2, steps - 1) + half];  // {a, b, c, weight}; broadcast per half-wave
-      Ops<T> nxt;
-      make_ops(q1, nxt);
+    // Software-pipelined K loop: the operands of step m+1 (VALU: 3..6 kernel vectors) are generated next to the
+    // 3*T*T MFMAs of step m.
+    // one K step: the MFMAs of `use` while the operands of the following step are generated into `gen` from qn; the
+    // float4 two steps ahead is fetched from LDS meanwhile (its latency is covered by a whole step of MFMAs even when
+    // the two waves of a SIMD run phase-locked)
+    auto kstep = [&](const Ops<T> &use, Ops<T> &gen, const float4 &qn, float4 &qf, int mf) __attribute__((always_inline)) {
+      qf = stage[wave * 64 + 2 * min(mf, steps - 1) + half];   // {a, b, c, weight}; broadcast per half-wave
+      make_ops(qn, gen);
 #pragma unroll
       for (int ti = 0; ti < T; ++ti)
 #pragma unroll
         for (int tj = 0; tj < T; ++tj) {
-          if (!green) acc[0][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A0[ti], cur.B0[tj], acc[0][ti][tj], 0, 0, 0);
-          acc[1][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A1[ti], cur.B1[tj], acc[1][ti][tj], 0, 0, 0);
-          if (!green) acc[2][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A2[ti], cur.B2[tj], acc[2][ti][tj], 0, 0, 0);
+          if (!green) acc[0][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(use.A0[ti], use.B0[tj], acc[0][ti][tj], 0, 0, 0);
+          acc[1][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(use.A1[ti], use.B1[tj], acc[1][ti][tj], 0, 0, 0);
+          if (!green) acc[2][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(use.A2[ti], use.B2[tj], acc[2][ti][tj], 0, 0, 0);
         }
 #if HG_FWD_SCHED_GROUPS
       // MFMAs in groups of HG_FWD_MFMA_GROUP with the operand generation of the next step between the groups.  On
@@ -315,10 +343,16 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
         __builtin_amdgcn_sched_group_barrier(0x002, HG_FWD_VALU_PER_MFMA * GRP, 0);
       }
 #endif
-      // pin: q2 is complete here (after a step's worth of MFMA issue), and is next iteration's q1
-      asm volatile("" : "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w));
-      q1 = q2;
-      cur = nxt;
+      // pin: qf is complete here (after a step's worth of MFMA issue)
+      asm volatile("" : "+v"(qf.x), "+v"(qf.y), "+v"(qf.z), "+v"(qf.w));
+    };
+    // two steps per iteration with the operand sets swapping roles: no register copies between steps
+    Ops<T> opA, opB;
+    make_ops(stage[wave * 64 + half], opA);
+    float4 qa = stage[wave * 64 + 2 * min(1, steps - 1) + half], qb;
+    for (int m = 0; m < steps; m += 2) {
+      kstep(opA, opB, qa, qb, m + 2);
+      if (m + 1 < steps) kstep(opB, opA, qb, qa, m + 3);
     }
     lds_wave_sync();
   }
@@ -536,12 +570,16 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
         o.kc = (fabs(ud[2] - bc) <= P.half_eps) ? 1.f : 0.f;
       } else {
         const float kf = -(float)b0;
-        const float ta = fmaf(kf, P.ds_hi, th[0]) + fmaf(kf, P.ds_lo, tl[0]);
-        const float tb = fmaf(kf, P.ds_hi, th[1]) + fmaf(kf, P.ds_lo, tl[1]);
+        // (a, b) as one packed-fp32 pair (v_pk_fma / v_pk_add: the same IEEE operations, half the instructions)
+        const f32x2 kf2 = {kf, kf};
+        const f32x2 tab = __builtin_elementwise_fma(kf2, f32x2{P.ds_hi, P.ds_hi}, f32x2{th[0], th[1]}) +
+                          __builtin_elementwise_fma(kf2, f32x2{P.ds_lo, P.ds_lo}, f32x2{tl[0], tl[1]});
+        const float ta = tab.x, tb = tab.y;
         const float tc = fmaf(kf, P.ds_hi, th[2]) + fmaf(kf, P.ds_lo, tl[2]);
         if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) {
-          o.ka = __builtin_amdgcn_rcpf(fmaf(ta, ta, 1.f));
-          o.kb = __builtin_amdgcn_rcpf(fmaf(tb, tb, 1.f));
+          const f32x2 dab = __builtin_elementwise_fma(tab, tab, f32x2{1.f, 1.f});
+          o.ka = __builtin_amdgcn_rcpf(dab.x);
+          o.kb = __builtin_amdgcn_rcpf(dab.y);
           o.kc = __builtin_amdgcn_rcpf(fmaf(tc, tc, 1.f));
         } else {
           o.ka = expf(-(ta * ta)); o.kb = expf(-(tb * tb)); o.kc = expf(-(tc * tc));
@@ -615,20 +653,48 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
 #pragma unroll
     for (int v = 0; v < 3; ++v) asm volatile("" : "+v"(th[v]), "+v"(tl[v]), "+v"(ud[v]));
     float gsum[3] = {0.f, 0.f, 0.f}, isum = 0.f;
+    if constexpr (METHOD != HG_METHOD_THRESHOLDING) {
+      // two consecutive bins per packed-fp32 operation: their accumulators are adjacent registers of one MFMA tile, the
+      // bin offsets compile-time pairs -- 8 v_pk_* + 2 transcendentals per two bins instead of 18 instructions
+      f32x2 gs2[3], is2 = {0.f, 0.f};
 #pragma unroll
-    for (int v = 0; v < 3; ++v)
+      for (int v = 0; v < 3; ++v) {
+        gs2[v] = f32x2{0.f, 0.f};
+        const f32x2 th2 = {th[v], th[v]}, tl2 = {tl[v], tl[v]};
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        float t;
-        const float kv = eval(v, s, t);
-        const float kw = kv * W[v][s >> 4][s & 15];
-        isum += kw;
-        if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) gsum[v] = fmaf(t * kv, kw, gsum[v]);
-        else if constexpr (METHOD == HG_METHOD_RBF) gsum[v] = fmaf(t, kw, gsum[v]);
+        for (int s = 0; s < NS; s += 2) {
+          const f32x2 kf2 = {-(float)beta0(s), -(float)beta0(s + 1)};
+          const f32x2 t2 = __builtin_elementwise_fma(kf2, f32x2{P.ds_hi, P.ds_hi}, th2) +
+                           __builtin_elementwise_fma(kf2, f32x2{P.ds_lo, P.ds_lo}, tl2);
+          f32x2 k2;
+          if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) {
+            const f32x2 d2 = __builtin_elementwise_fma(t2, t2, f32x2{1.f, 1.f});
+            k2 = f32x2{__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)};
+          } else {
+            k2 = f32x2{expf(-(t2.x * t2.x)), expf(-(t2.y * t2.y))};
+          }
+          const f32x2 w2 = {W[v][s >> 4][s & 15], W[v][s >> 4][(s & 15) + 1]};
+          const f32x2 kw2 = k2 * w2;
+          is2 += kw2;
+          if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) gs2[v] = __builtin_elementwise_fma(t2 * k2, kw2, gs2[v]);
+          else gs2[v] = __builtin_elementwise_fma(t2, kw2, gs2[v]);
 #if HG_BWD_SCHED_BARRIER
-        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // keep the re-evaluations from being hoisted en bloc
+          if ((s & 7) == 6) __builtin_amdgcn_sched_barrier(0);  // keep the re-evaluations from being hoisted en bloc
 #endif
+        }
+        gsum[v] = gs2[v].x + gs2[v].y;
       }
+      isum = is2.x + is2.y;
+    } else {
+#pragma unroll
+      for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          float t;
+          const float kv = eval(v, s, t);
+          isum += kv * W[v][s >> 4][s & 15];
+        }
+    }
 #pragma unroll
     for (int v = 0; v < 3; ++v) gsum[v] += __shfl_xor(gsum[v], 32, 64);
     isum += __shfl_xor(isum, 32, 64);
@@ -727,8 +793,15 @@ __global__ __launch_bounds__(256, 2) void k_hist_bwd_planes(const DevParams P, c
           op.Av[rt] = G[beta * LD + row];
         }
         const float kf = -(float)b0;
-        op.ku = kern(fmaf(kf, P.ds_hi, th[0]) + fmaf(kf, P.ds_lo, tl[0]));
-        op.kv = kern(fmaf(kf, P.ds_hi, th[1]) + fmaf(kf, P.ds_lo, tl[1]));
+        const f32x2 kf2 = {kf, kf};                      // (u, v) as one packed-fp32 pair
+        const f32x2 tuv = __builtin_elementwise_fma(kf2, f32x2{P.ds_hi, P.ds_hi}, f32x2{th[0], th[1]}) +
+                          __builtin_elementwise_fma(kf2, f32x2{P.ds_lo, P.ds_lo}, f32x2{tl[0], tl[1]});
+        if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) {
+          const f32x2 d2 = __builtin_elementwise_fma(tuv, tuv, f32x2{1.f, 1.f});
+          op.ku = __builtin_amdgcn_rcpf(d2.x); op.kv = __builtin_amdgcn_rcpf(d2.y);
+        } else {
+          op.ku = kern(tuv.x); op.kv = kern(tuv.y);
+        }
       };
       POps<RT> cur;
       make_ops(0, cur);
@@ -756,20 +829,38 @@ __global__ __launch_bounds__(256, 2) void k_hist_bwd_planes(const DevParams P, c
 
       // epilogue: this lane holds W*[t][r] for bin beta0(16t+r)+4*half of pixel q; kernel values re-evaluated
       asm volatile("" : "+v"(th[0]), "+v"(tl[0]), "+v"(th[1]), "+v"(tl[1]));
-      float gu = 0.f, gv = 0.f, isum = 0.f;
+      float gu, gv, isum;
+      {
+        // two consecutive bins per packed-fp32 operation (adjacent accumulator registers), as in k_hist_bwd
+        f32x2 gu2 = {0.f, 0.f}, gv2 = {0.f, 0.f}, is2 = {0.f, 0.f};
+        auto kern2 = [&](const f32x2 &t) __attribute__((always_inline)) -> f32x2 {
+          if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) {
+            const f32x2 d = __builtin_elementwise_fma(t, t, f32x2{1.f, 1.f});
+            return f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+          } else {
+            return f32x2{expf(-(t.x * t.x)), expf(-(t.y * t.y))};
+          }
+        };
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const float kf = -(float)beta0(s);
-        const float tu = fmaf(kf, P.ds_hi, th[0]) + fmaf(kf, P.ds_lo, tl[0]);
-        const float tv = fmaf(kf, P.ds_hi, th[1]) + fmaf(kf, P.ds_lo, tl[1]);
-        const float ku = kern(tu), kv = kern(tv);
-        const float kwu = ku * Wu[s >> 4][s & 15], kwv = kv * Wv[s >> 4][s & 15];
-        isum += kwu;
-        if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) { gu = fmaf(tu * ku, kwu, gu); gv = fmaf(tv * kv, kwv, gv); }
-        else { gu = fmaf(tu, kwu, gu); gv = fmaf(tv, kwv, gv); }
+        for (int s = 0; s < NS; s += 2) {
+          const f32x2 kf2 = {-(float)beta0(s), -(float)beta0(s + 1)};
+          const f32x2 dsh = {P.ds_hi, P.ds_hi}, dsl = {P.ds_lo, P.ds_lo};
+          const f32x2 tu = __builtin_elementwise_fma(kf2, dsh, f32x2{th[0], th[0]}) + __builtin_elementwise_fma(kf2, dsl, f32x2{tl[0], tl[0]});
+          const f32x2 tv = __builtin_elementwise_fma(kf2, dsh, f32x2{th[1], th[1]}) + __builtin_elementwise_fma(kf2, dsl, f32x2{tl[1], tl[1]});
+          const f32x2 ku = kern2(tu), kv = kern2(tv);
+          const f32x2 kwu = ku * f32x2{Wu[s >> 4][s & 15], Wu[s >> 4][(s & 15) + 1]};
+          const f32x2 kwv = kv * f32x2{Wv[s >> 4][s & 15], Wv[s >> 4][(s & 15) + 1]};
+          is2 += kwu;
+          if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) {
+            gu2 = __builtin_elementwise_fma(tu * ku, kwu, gu2); gv2 = __builtin_elementwise_fma(tv * kv, kwv, gv2);
+          } else {
+            gu2 = __builtin_elementwise_fma(tu, kwu, gu2); gv2 = __builtin_elementwise_fma(tv, kwv, gv2);
+          }
 #if HG_BWD_SCHED_BARRIER
-        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+          if ((s & 7) == 6) __builtin_amdgcn_sched_barrier(0);
 #endif
+        }
+        gu = gu2.x + gu2.y; gv = gv2.x + gv2.y; isum = is2.x + is2.y;
       }
       gu += __shfl_xor(gu, 32, 64);
       gv += __shfl_xor(gv, 32, 64);
