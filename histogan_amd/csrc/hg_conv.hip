@@ -21,6 +21,8 @@
 //
 // Pixel tiles are NI images x TH rows x TW columns (all powers of two, chosen on the host per layer:
 // 32-wide rows for big maps, several whole images per tile for 4x4 / 8x8 maps).
+#include <cstdio>
+#include <cstdlib>
 #include "hg_common.h"
 #include "../../include/hg_hist.h"
 #include "../../include/hg_conv.h"
@@ -82,6 +84,20 @@ __device__ __forceinline__ int fdiv(int e, float inv) {  // floor(e / d) for 0 <
   return (int)(((float)e + 0.5f) * inv);
 }
 
+// Buffer (SRSRC) loads for the operand staging: a 32-bit byte offset per lane against a wave-uniform base, and the
+// hardware range check turns an offset of 0xFFFFFFFF into a load of 0.0 without touching memory -- zero padding,
+// batch tails and lanes without an element cost no predicate, no branch and no s_waitcnt behind the load.
+constexpr unsigned kOOB = 0xFFFFFFFFu;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)kOOB, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+
 // ------------------------------------------------------------------------------------------------
 // output / data-gradient kernel
 // MT = MFMA tile: 32 (v_mfma_f32_32x32x2_f32, 2 channels per instruction) or 16 (v_mfma_f32_16x16x4_f32, 4 channels
@@ -141,13 +157,16 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
   const int n0 = blockIdx.y * NB;
   const int TWm = (1 << g.lTW) - 1, THm = (1 << g.lTH) - 1;
 
-  // ---- staging descriptors of the halo tile (chunk-invariant)
-  int goff[NH];
+  // ---- staging descriptors of the halo tile (chunk-invariant): byte offset of the element against this block's first
+  //      image (kOOB: zero padding / no element), and the LDS slot it is written to (spare lanes: a dump row behind Xs)
+  unsigned voff[NH];
+  int xso[NH];
   const int htot = KC * g.HALO;
 #pragma unroll
   for (int i = 0; i < NH; ++i) {
     const int e = tid + i * NT;
-    goff[i] = -1;
+    voff[i] = kOOB;
+    xso[i] = KC * g.CHS + lane;
     if (e < htot) {
       const int kc = fdiv(e, g.inv_HALO);
       const int r = e - kc * g.HALO;
@@ -156,17 +175,24 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
       const int hy = fdiv(rr, g.inv_TWp);
       const int hx = rr - hy * g.TWp;
       const int gy = y0 * IS + g.lo_y + hy, gx = x0 * IS + g.lo_x + hx, b = b0 + img;
+      xso[i] = kc * g.CHS + r;
       if (b < a.B && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi)
-        goff[i] = ((b * K + kc) * Hi + gy) * Wi + gx;
+        voff[i] = (unsigned)(((img * K + kc) * Hi + gy) * Wi + gx) * 4u;
     }
   }
-  // weight staging: element id = tid + i*NT -> (tap, float4 in the tap's [KC][NB] slice); the packed row of the tap
-  int wrow[NW];
+  // weight staging: element id = tid + i*NT -> (tap, float4 in the tap's [KC][NB] slice); byte offset in the packed
+  // weights for chunk 0 (the chunk advances through the scalar offset of the load)
+  unsigned wv[NW];
 #pragma unroll
   for (int i = 0; i < NW; ++i) {
-    const int t = (tid + i * NT) / WPT;
-    wrow[i] = t < TAPS ? a.wrow0 + (t / a.ntx) * a.wrow_dy + (t % a.ntx) * a.wrow_dx : 0;
+    const int id = tid + i * NT;
+    const int t = id / WPT, e4 = id % WPT;
+    const int kc = e4 / (NB / 4), c4 = e4 % (NB / 4);
+    const int wrow = t < TAPS ? a.wrow0 + (t / a.ntx) * a.wrow_dy + (t % a.ntx) * a.wrow_dx : 0;
+    wv[i] = (NW * NT == WTOT || id < WTOT) ? (unsigned)((wrow + kc) * a.Np + n0 + c4 * 4) * 4u : kOOB;
   }
+  // LDS slot (in float4) of weight element i: spare lanes of the last pass write a dump row behind the operands
+  const int wdump = (TAPS * KC * NB + KC * g.CHS + 64) / 4 + 1 + lane;
 
   // ---- operand read offsets
   int pixoff[TP];
@@ -188,14 +214,17 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
 
   float xr[NH];
   float xs[FE ? NH : 1];     // modulation scale of each staged element (only live when iscale is given)
-  int soff[FE ? NH : 1];     // (b*K + kc) of each staged element
+  unsigned soff[FE ? NH : 1];     // byte offset of (b*K + kc) of each staged element in iscale (kOOB: none)
   if (FE && a.iscale != nullptr) {
 #pragma unroll
     for (int i = 0; i < NH; ++i) {
-      const int e0 = tid + i * NT, e = e0 < htot ? e0 : 0;
-      const int kc = fdiv(e, g.inv_HALO);
-      const int bb = b0 + fdiv(e - kc * g.HALO, g.inv_IMS);
-      soff[i] = (bb < a.B ? bb : a.B - 1) * K + kc;
+      const int e = tid + i * NT;
+      soff[i] = kOOB;
+      if (e < htot) {
+        const int kc = fdiv(e, g.inv_HALO);
+        const int bb = b0 + fdiv(e - kc * g.HALO, g.inv_IMS);
+        if (bb < a.B) soff[i] = (unsigned)(bb * K + kc) * 4u;
+      }
     }
   }
   f32x4 wr[NW];
@@ -204,46 +233,44 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
   const int c_begin = blockIdx.z * cps;
   const int nchunks = c_begin + cps < nchunks_all ? c_begin + cps : nchunks_all;
   const int HWi = Hi * Wi;
+  const float *inblk = a.in + (size_t)b0 * K * HWi;          // first image of this block (wave-uniform)
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wt), rs = make_rsrc(FE && a.iscale ? a.iscale : a.wt);
 
+  // All loads are unconditional (a `valid ? load : 0` select makes the compiler branch around every load and wait for
+  // it at once: the global latency then runs in series with the MFMAs of the chunk).
   auto prefetch = [&](int c) __attribute__((always_inline)) {
-    const float *inb = a.in + (size_t)c * KC * HWi;
-    const int krem = K - c * KC;  // channels left
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(inblk + (size_t)c * KC * HWi);
+    if (K - c * KC < KC) {   // the last, partial chunk (once per block): channels past the end read as zero from here on
+      const int krem = K - c * KC;
 #pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      bool ok = goff[i] >= 0;
-      if (krem < KC) ok = ok && fdiv(tid + i * NT, g.inv_HALO) < krem;   // last, partial chunk only
-      xr[i] = ok ? inb[goff[i]] : 0.f;
-      if constexpr (FE) {
-        if (a.iscale != nullptr) {   // unconditional (clamped) load; multiplied in at the LDS store
-          const int si = soff[i] + c * KC;
-          xs[i] = a.iscale[si < a.B * K ? si : a.B * K - 1];
+      for (int i = 0; i < NH; ++i)
+        if (fdiv(tid + i * NT, g.inv_HALO) >= krem) {
+          voff[i] = kOOB;
+          if constexpr (FE) soff[i] = kOOB;
         }
-      }
     }
-    const float *wb = a.wt + (size_t)c * KC * a.Np + n0;
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int id = tid + i * NT;
-      if (NW * NT == WTOT || id < WTOT) {
-        const int e4 = id % WPT;
-        const int kc = e4 / (NB / 4), c4 = e4 % (NB / 4);
-        wr[i] = *reinterpret_cast<const f32x4 *>(wb + ((size_t)wrow[i] + kc) * a.Np + c4 * 4);
+    for (int i = 0; i < NH; ++i) xr[i] = buf_load(rx, voff[i], 0);
+    if constexpr (FE) {
+      if (a.iscale != nullptr) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) xs[i] = buf_load(rs, soff[i], c * KC * 4);
       }
     }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) wr[i] = buf_load4(rw, wv[i], c * KC * a.Np * 4);
   };
 
   for (int c = c_begin - 1; c < nchunks; ++c) {
     if (c >= c_begin) {
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < NH; ++i) {
-        const int e = tid + i * NT;
-        if (e < htot) Xs[fdiv(e, g.inv_HALO) * (g.CHS - g.HALO) + e] = (FE && a.iscale != nullptr) ? xr[i] * xs[FE ? i : 0] : xr[i];
-      }
+      for (int i = 0; i < NH; ++i) Xs[xso[i]] = (FE && a.iscale != nullptr) ? xr[i] * xs[FE ? i : 0] : xr[i];
 #pragma unroll
       for (int i = 0; i < NW; ++i) {
         const int id = tid + i * NT;
-        if (NW * NT == WTOT || id < WTOT) reinterpret_cast<f32x4 *>(Ws)[id] = wr[i];
+        if (NW * NT == WTOT || i + 1 < NW) reinterpret_cast<f32x4 *>(Ws)[id] = wr[i];
+        else reinterpret_cast<f32x4 *>(Ws)[id < WTOT ? id : wdump] = wr[i];
       }
       __syncthreads();
     }
@@ -264,6 +291,10 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
       for (int j = 0; j < TP; ++j) bv[slot][j] = Xs[pixoff[j] + toff + kk * KS * g.CHS];
     };
     ldop(0, 0);
+    // pin the schedule: [operand reads of step s+1] [MFMAs of step s] (the compiler otherwise batches the pixel-operand
+    // reads of several steps and issues the weight reads just in time, behind an s_waitcnt lgkmcnt(0) per step)
+    constexpr int DSN = (MT == 32 ? (TC + 1) / 2 : TC) + TP;
+    __builtin_amdgcn_sched_group_barrier(0x100, DSN, 0);
 #if HG_CONV_SETPRIO > 0
     __builtin_amdgcn_s_setprio(HG_CONV_SETPRIO);   // waves in their MFMA phase go first: the staging of other waves fills in
 #elif HG_CONV_SETPRIO < 0
@@ -276,6 +307,11 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
       for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = M::mma(av[s_ & 1][i], bv[s_ & 1][j], acc[i][j]);
+      if (s_ + 1 < NS) {
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);     // address of the next weight read
+        __builtin_amdgcn_sched_group_barrier(0x100, DSN, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, TC * TP, 0);
     }
 #if HG_CONV_SETPRIO > 0
     __builtin_amdgcn_s_setprio(0);
@@ -871,6 +907,43 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
 
 inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st);
 
+// How many blocks per CU should a launch of `nwg` equal blocks run with?  The MFMA kernels here are resident-block
+// bound: a CU with c blocks in flight sustains e[c] of the matrix peak (measured, tools/occ_probe.py: 0.71 / 0.85 / 0.90
+// for 1 / 2 / 3 blocks of the 128x128 tile), and a launch whose block count is not a multiple of (CUs x c) ends in a
+// round at low occupancy that the dispatcher also balances badly (1024 blocks at c = 3: 104 TFLOP/s, at c = 2: 134).
+constexpr size_t kLdsPerCu = 160 * 1024;
+inline int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+inline int pick_blocks_per_cu(long long nwg, int cmax) {
+  static const int forced = getenv("HG_CONV_OCC") ? atoi(getenv("HG_CONV_OCC")) : 0;   // experiments: fixed cap
+  if (forced > 0) return forced < cmax ? forced : cmax;
+  static const double e[9] = {0, 0.71, 0.85, 0.90, 0.92, 0.93, 0.93, 0.93, 0.93};
+  if (cmax > 8) cmax = 8;
+  const double cus = (double)num_cus();
+  int best = cmax;
+  double best_t = 1e300;
+  for (int c = cmax; c >= 1; --c) {
+    const long long per_round = (long long)cus * c;
+    const long long full = nwg / per_round, rem = nwg - full * per_round;
+    double t = (double)full * c / e[c];
+    if (rem > 0) {
+      int cr = (int)((rem + (long long)cus - 1) / (long long)cus);
+      if (full > 0) cr = 2 * cr < c ? 2 * cr : c;   // freed slots are refilled greedily: the tail lands unevenly
+      t += cr / e[cr];
+    }
+    if (t < best_t * 0.995) { best_t = t; best = c; }
+  }
+  return best;
+}
+
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM = false, int MT = 32>
 int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t st) {
   constexpr int NB = WC * TC * MT, MB = WP * TP * MT, NT = WC * WP * 64;
@@ -887,12 +960,35 @@ int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t
   a.wrow_dx = tp.ntx > 1 ? (tp.w[1] - tp.w[0]) * a.Kp : 0;
   a.wrow_dy = TAPS > tp.ntx ? (tp.w[tp.ntx] - tp.w[0]) * a.Kp : 0;
   a.ksplit = ksplit;
-  const size_t lds = ((size_t)TAPS * KC * NB + (size_t)KC * a.g.CHS) * sizeof(float);
+  // + dump rows for the spare staging lanes: 64 floats (halo) and, 16-byte aligned behind them, 64 float4 (weights)
+  size_t lds = ((size_t)TAPS * KC * NB + (size_t)KC * a.g.CHS + 64 + 8 + 256) * sizeof(float);
+  // the halo loads address one block's images with 32-bit byte offsets
+  if ((long long)(1 << a.g.lNI) * a.K * a.Hi * a.Wi >= (1LL << 30)) return HG_EUNSUPPORTED;
   const bool fe = a.iscale || a.oscale || a.noise_img || a.slope > 0.f;
   auto kern = fe ? k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, true> : k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, false>;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // blocks per CU for THIS launch (see pick_blocks_per_cu): fewer than the registers allow when that makes the block
+  // count a whole number of rounds; enforced by asking for more LDS than 1/(c+1) of a CU's
+  static int cmax[2] = {0, 0};
+  if (!cmax[fe]) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, NT, lds) != hipSuccess || n < 1) n = 1;
+    cmax[fe] = n;
+  }
+  const long long nwg = (long long)a.g.tiles_x * a.g.tiles_y * a.g.groups * ((a.N + NB - 1) / NB) * ksplit;
+  const int by_lds = (int)(kLdsPerCu / lds), cm = by_lds < cmax[fe] ? (by_lds > 1 ? by_lds : 1) : cmax[fe];
+  const int c = pick_blocks_per_cu(nwg, cm);
+  if (c < cm) {
+    const size_t need = (size_t)kLdsPerCu / (c + 1) + 512;
+    if (lds < need) lds = need;
+  }
+  static const bool dbg = getenv("HG_CONV_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "k_conv<%d,%d,%d,%d,taps %d,kc %d,is %d,mt %d,fe %d>: %lld blocks, max %d (registers %d) -> %d per CU, lds %zu\n",
+                   WC, WP, TC, TP, TAPS, KC, IS, MT, (int)fe, nwg, cm, cmax[fe], c, lds);
+  static bool big_lds[2] = {false, false};   // dynamic LDS above 48 KB has to be allowed once per kernel
+  if (lds > 48 * 1024 && !big_lds[fe]) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
     if (e != hipSuccess) return (int)e;
+    big_lds[fe] = true;
   }
   const dim3 grid((unsigned)(a.g.tiles_x * a.g.tiles_y * a.g.groups), (unsigned)((a.N + NB - 1) / NB), (unsigned)ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);

@@ -1,0 +1,183 @@
+// What separates k_conv's 128x128 tile (0.79 of the fp32-MFMA peak) from a bare MFMA loop (0.95)?  The K loop of k_conv
+// rebuilt piece by piece: 4 accumulators per wave (2 x 2 MFMA tiles), 18 steps of 4 MFMAs per chunk (9 taps x 2 k-steps),
+// 4 waves per block, 2 blocks per CU.
+//   OPS   0: operands in registers      1: operands from LDS as k_conv reads them (1 ds_read2_b32 + 2 ds_read_b32 + 1 v_add
+//            per 4 MFMAs, one step ahead)   2: wide reads (1 ds_read_b128 + 2 ds_read_b64 per 8 MFMAs)
+//   BAR   two s_barrier per chunk (72 MFMAs)
+//   STAGE 4 dword + 5 dwordx4 global loads per thread and chunk, written to LDS between the barriers
+//   hipcc --offload-arch=gfx950 -O3 mfma_conv_loop.hip -o mfma_conv_loop && ./mfma_conv_loop
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Args {
+  const float *in;
+  float *out;
+  int nchunks;
+  int toff[9];
+  int stride;
+};
+
+constexpr int WS = 9 * 4 * 128;   // weight floats per chunk
+constexpr int XS = 4 * 832;       // halo floats per chunk (6 x 34 halo of a 4 x 32 tile, padded)
+
+template <int OPS, int BAR, int STAGE>
+__global__ __launch_bounds__(256, 2) void kc(const Args a) {
+  __shared__ float lds[WS + XS + 64];
+  float *Ws = lds, *Xs = lds + WS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 31, lk = lane >> 5, wc = wave & 1, wp = wave >> 1;
+  for (int i = tid; i < WS + XS; i += 256) lds[i] = a.in[i];
+  __syncthreads();
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int aoff = lk * 128 + wc * 64 + lm;
+  int pixoff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = (wp * 2 + j) * 32 + lm;
+    pixoff[j] = (p >> 5) * 34 + (p & 31) + lk * 832;
+  }
+  float xr[4];
+  f32x4 wr[5];
+  const float *base = a.in + (size_t)(blockIdx.x & 63) * 65536;
+  auto prefetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[i] = base[(c & 7) * a.stride + tid + i * 256];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wr[i] = *reinterpret_cast<const f32x4 *>(base + 16384 + (c & 7) * a.stride + (tid + i * 256) * 4);
+  };
+  float ra = a.in[tid], rb = a.in[tid + 256];
+  for (int c = -1; c < a.nchunks; ++c) {
+    if (c >= 0) {
+      if (BAR) __syncthreads();
+      if (STAGE) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (tid + i * 256 < XS) Xs[tid + i * 256] = xr[i];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+          if (tid + i * 256 < WS / 4) reinterpret_cast<f32x4 *>(Ws)[tid + i * 256] = wr[i];
+      }
+      if (BAR) __syncthreads();
+    }
+    if (STAGE && c + 1 < a.nchunks) prefetch(c + 1);
+    if (c < 0) continue;
+    if (!BAR) asm volatile("" ::: "memory");   // the LDS reads stay inside the chunk loop
+    if constexpr (OPS == 0) {
+#pragma unroll
+      for (int s = 0; s < 18; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra, rb, acc[i][j], 0, 0, 0);
+    } else if constexpr (OPS == 1) {
+      float av[2][2], bv[2][2];
+      auto ldop = [&](int s, int slot) __attribute__((always_inline)) {
+        const int t = s / 2, kk = s % 2;
+        const int toff = a.toff[t];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[slot][i] = Ws[(t * 4 + kk * 2) * 128 + aoff + i * 32];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[slot][j] = Xs[pixoff[j] + toff + kk * 2 * 832];
+      };
+      ldop(0, 0);
+#pragma unroll
+      for (int s = 0; s < 18; ++s) {
+        if (s + 1 < 18) ldop(s + 1, (s + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // wide: A for (2 k-steps x 2 channel tiles) of a tap in one b128, B for 2 k-steps of a pixel tile in one b64
+      f32x4 av[2];
+      f32x2 bv[2][2];
+      auto ldop = [&](int t, int slot) __attribute__((always_inline)) {
+        const int toff = a.toff[t];
+        av[slot] = *reinterpret_cast<const f32x4 *>(Ws + ((t * 2 + lk) * 64 + wc * 32 + lm) * 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[slot][j] = *reinterpret_cast<const f32x2 *>(Xs + (pixoff[j] + toff) * 2 - lk * 832);
+      };
+      ldop(0, 0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) ldop(t + 1, (t + 1) & 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t & 1][i * 2 + kk], bv[t & 1][j][kk], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  a.out[blockIdx.x * 256 + tid] = s;
+}
+
+template <int OPS, int BAR, int STAGE>
+void run(Args a, int grid, const char *what) {
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float ms = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((kc<OPS, BAR, STAGE>), dim3(grid), dim3(256), 0, 0, a);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+  }
+  const double flop = (double)grid * 4 * a.nchunks * 72 * 4096.0;
+  printf("%-58s grid %4d: %7.3f ms  %6.1f TFLOP/s (%.3f of 157.3)\n", what, grid, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3);
+}
+
+int main(int argc, char **argv) {
+  Args a;
+  float *in, *out;
+  (void)hipMalloc(&in, 64 * 65536 * 4 + (1 << 20));
+  (void)hipMemset(in, 0, 64 * 65536 * 4 + (1 << 20));
+  if (argc > 1) {   // random operands (data-dependent power): any argument
+    const size_t n = 64 * 65536 + (1 << 18);
+    float *h = (float *)malloc(n * 4);
+    unsigned x = 12345u;
+    for (size_t i = 0; i < n; ++i) { x = x * 1664525u + 1013904223u; h[i] = ((int)(x >> 8) - (1 << 23)) * (1.0f / (1 << 20)); }
+    (void)hipMemcpy(in, h, n * 4, hipMemcpyHostToDevice);
+    free(h);
+    printf("random operands\n");
+  }
+  (void)hipMalloc(&out, 4096 * 256 * 4);
+  a.in = in;
+  a.out = out;
+  a.nchunks = 64 * 4;
+  a.stride = 4096;
+  for (int t = 0; t < 9; ++t) a.toff[t] = (t / 3) * 34 + t % 3;
+  a.nchunks = 64 * 4 * (argc > 2 ? atoi(argv[2]) : 1);
+  for (int round = 0; round < 2; ++round) {
+    const int grid = 512;
+    run<0, 0, 0>(a, grid, "registers, no barrier");
+    run<1, 1, 0>(a, grid, "LDS operands, 2 barriers");
+    run<1, 1, 1>(a, grid, "LDS operands, 2 barriers, staging (= k_conv loop)");
+    run<2, 1, 0>(a, grid, "wide LDS operands, 2 barriers");
+    run<2, 1, 1>(a, grid, "wide LDS operands, 2 barriers, staging");
+    run<0, 0, 0>(a, grid, "registers, no barrier");
+  }
+  return 0;
+}
