@@ -88,9 +88,10 @@ __device__ __forceinline__ int fdiv(int e, float inv) {  // floor(e / d) for 0 <
 // hardware range check turns an offset of 0xFFFFFFFF into a load of 0.0 without touching memory -- zero padding,
 // batch tails and lanes without an element cost no predicate, no branch and no s_waitcnt behind the load.
 constexpr unsigned kOOB = 0xFFFFFFFFu;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)kOOB, 0x00020000);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, unsigned bytes = kOOB) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000);
 }
+constexpr unsigned kFar = 0x80000000u;   // an out-of-range offset that stays out of range when < 2 GB is added to it
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
 }
@@ -510,14 +511,13 @@ __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a
   const int himg = hrr / G::IMS, hy = (hrr % G::IMS) / G::TWp, hx = hrr % G::TWp;
   const bool hlane = hcs < HCPI;
 
-  // Prefetch loads are UNCONDITIONAL (a `valid ? load : 0` select puts an s_waitcnt right behind every load and
-  // serialises the global latency with the MFMAs -- with one block per CU nothing else hides it).  Positions outside
-  // the image / channels past the end load the nearest valid element instead (clamped coordinates: distinct, local
-  // addresses) and are zeroed when the registers are stored to LDS (static channel masks x per-chunk pixel validity).
-  const int hcs2 = hlane ? hcs : 0;                       // spare lanes mirror a position of channel slot 0
-  const int gdl = N - 1 - (n0 + gcs) > 0 ? N - 1 - (n0 + gcs) : 0;   // largest channel step that stays < N
-  const int hdl = K - 1 - (k0 + hcs2) > 0 ? K - 1 - (k0 + hcs2) : 0;
-  const int gc0 = n0 + gcs < N ? n0 + gcs : N - 1, hc0 = k0 + hcs2 < K ? k0 + hcs2 : K - 1;
+  // Prefetch loads are UNCONDITIONAL buffer loads (a `valid ? load : 0` select puts an s_waitcnt right behind every
+  // load and serialises the global latency with the MFMAs -- with one block per CU nothing else hides it): a position
+  // outside the image, a channel past the end or a spare lane carries the byte offset kOOB, for which the hardware
+  // range check returns 0.0 without a memory access -- no clamped coordinates, no select at the LDS store.  The base of
+  // the descriptor is the chunk's first image and this block's first channel (wave-uniform), the channel of pass i
+  // goes through the scalar offset; per chunk a thread computes ONE offset for its gout pixel and ONE for its halo
+  // position.
   unsigned gstat = 0;
   unsigned long long hstat = 0;
   static_assert(NGI <= 32 && NHI <= 64, "validity masks");
@@ -540,24 +540,50 @@ __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a
     const int grp = pt / a.tiles_y;
     const int x0 = tx * G::TW, y0 = ty * G::TH, b0 = grp * G::NI;
     pb0 = b0;
-    {
-      const int gx = x0 + gpx, gy = y0 + gpy, b = b0 + gpi;
-      const bool ok = b < a.B && gy < Ho && gx < Wo;
-      const int cb = b < a.B ? b : a.B - 1, cy = gy < Ho ? gy : Ho - 1, cx = gx < Wo ? gx : Wo - 1;
-      const unsigned off = (unsigned)(cb * N + gc0) * (unsigned)HWo + (unsigned)(cy * Wo + cx);
+    if constexpr (G::NI == 1) {
+      // one image per chunk: the byte offset grows with the channel, so the descriptor's size ends the valid channels
+      // (offset < (N - n0) * HWo * 4  <=>  channel < N) and the passes just step the offset -- no per-pass masks
+      const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.gout + ((size_t)b0 * N + n0) * HWo, (unsigned)(N - n0) * (unsigned)HWo * 4u);
+      const int gx = x0 + gpx, gy = y0 + gpy;
+      const bool ok = gy < Ho && gx < Wo;
+      unsigned off = ok ? (unsigned)(gcs * HWo + gy * Wo + gx) * 4u : kFar;
       gmask = ok ? gstat : 0u;
+      const unsigned gstep = (unsigned)(GCPI * HWo) * 4u;
 #pragma unroll
-      for (int i = 0; i < NGI; ++i) gr[i] = a.gout[off + (unsigned)(i * GCPI < gdl ? i * GCPI : gdl) * (unsigned)HWo];
-    }
-    {
-      const int gy = y0 * IS + hy - PAD, gx = x0 * IS + hx - PAD, b = b0 + himg;
-      const bool ok = b < a.B && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi;
-      const int cb = b < a.B ? b : a.B - 1;
-      const int cy = gy < 0 ? 0 : (gy >= Hi ? Hi - 1 : gy), cx = gx < 0 ? 0 : (gx >= Wi ? Wi - 1 : gx);
-      const unsigned off = (unsigned)(cb * K + hc0) * (unsigned)HWi + (unsigned)(cy * Wi + cx);
-      hmask = ok ? hstat : 0ull;
+      for (int i = 0; i < NGI; ++i) {
+        gr[i] = buf_load(rg, off, 0);
+        off += gstep;
+      }
+      const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.in + ((size_t)b0 * K + k0) * HWi, (unsigned)(K - k0) * (unsigned)HWi * 4u);
+      const int hgy = y0 * IS + hy - PAD, hgx = x0 * IS + hx - PAD;
+      const bool hok = hlane && (unsigned)hgy < (unsigned)Hi && (unsigned)hgx < (unsigned)Wi;
+      unsigned hoff = hok ? (unsigned)(hcs * HWi + hgy * Wi + hgx) * 4u : kFar;
+      hmask = hok ? hstat : 0ull;
+      const unsigned hstep = (unsigned)(HCPI * HWi) * 4u;
 #pragma unroll
-      for (int i = 0; i < NHI; ++i) hr[i] = a.in[off + (unsigned)(i * HCPI < hdl ? i * HCPI : hdl) * (unsigned)HWi];
+      for (int i = 0; i < NHI; ++i) {
+        hr[i] = buf_load(rh, hoff, 0);
+        hoff += hstep;
+      }
+    } else {
+      {
+        const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.gout + ((size_t)b0 * N + n0) * HWo);
+        const int gx = x0 + gpx, gy = y0 + gpy, b = b0 + gpi;
+        const bool ok = b < a.B && gy < Ho && gx < Wo;
+        const unsigned off = ok ? (unsigned)((gpi * N + gcs) * HWo + gy * Wo + gx) * 4u : kOOB;
+        gmask = ok ? gstat : 0u;
+#pragma unroll
+        for (int i = 0; i < NGI; ++i) gr[i] = buf_load(rg, (gmask >> i) & 1u ? off + (unsigned)(i * GCPI * HWo) * 4u : kOOB, 0);
+      }
+      {
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.in + ((size_t)b0 * K + k0) * HWi);
+        const int gy = y0 * IS + hy - PAD, gx = x0 * IS + hx - PAD, b = b0 + himg;
+        const bool ok = b < a.B && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi;
+        const unsigned off = ok ? (unsigned)((himg * K + hcs) * HWi + gy * Wi + gx) * 4u : kOOB;
+        hmask = ok ? hstat : 0ull;
+#pragma unroll
+        for (int i = 0; i < NHI; ++i) hr[i] = buf_load(rh, (hmask >> i) & 1ull ? off + (unsigned)(i * HCPI * HWi) * 4u : kOOB, 0);
+      }
     }
   };
 
@@ -568,17 +594,30 @@ __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a
   constexpr int NBUF = ((WS == 1 || (TS > 1 && HG_WGRAD_TS_DBUF)) && 2 * BUFSZ * 4 <= 160 * 1024) ? 2 : 1;
   auto store = [&](int buf) __attribute__((always_inline)) {
     float *G2 = smem + buf * BUFSZ, *X2 = G2 + NBW * GP;
+    if (a.gscale == nullptr && a.iscale == nullptr) {
+      // the training hot path: registers straight to LDS (invalid positions were loaded as 0.0); only the last pass of
+      // each operand can address a channel row outside the block tile
+#pragma unroll
+      for (int i = 0; i < NGI; ++i)
+        if (NGI * GCPI == NBW || i + 1 < NGI || gcs + i * GCPI < NBW) G2[(gcs + i * GCPI) * GP + gp] = gr[i];
+      if (hlane) {
+#pragma unroll
+        for (int i = 0; i < NHI; ++i)
+          if (NHI * HCPI == KBW || i + 1 < NHI || hcs + i * HCPI < KBW) X2[(hcs + i * HCPI) * G::CHS + hrr] = hr[i];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NGI; ++i)
       if (NGI * GCPI == NBW || gcs + i * GCPI < NBW) {
-        float v = (gmask >> i) & 1u ? gr[i] : 0.f;
+        float v = gr[i];   // invalid positions were loaded as 0
         if (a.gscale != nullptr && ((gmask >> i) & 1u)) v *= a.gscale[(pb0 + gpi) * N + n0 + gcs + i * GCPI];
         G2[(gcs + i * GCPI) * GP + gp] = v;
       }
 #pragma unroll
     for (int i = 0; i < NHI; ++i)
       if (hlane && (NHI * HCPI == KBW || hcs + i * HCPI < KBW)) {
-        float v = (hmask >> i) & 1ull ? hr[i] : 0.f;
+        float v = hr[i];
         if (a.iscale != nullptr) {
           if constexpr (G::NI == 1) {
             // one image per chunk: the HCPI candidate scales of pass i are wave-uniform -> scalar loads + select
@@ -847,10 +886,66 @@ struct ConvPlan {
   int ksplit;
 };
 
+// How many blocks per CU should a launch of `nwg` equal blocks run with?  The MFMA kernels here are resident-block
+// bound: a CU with c blocks in flight sustains e[c] of the matrix peak (measured, tools/occ_probe.py: 0.71 / 0.85 / 0.90
+// for 1 / 2 / 3 blocks of the 128x128 tile), and a launch whose block count is not a multiple of (CUs x c) ends in a
+// round at low occupancy that the dispatcher also balances badly (1024 blocks at c = 3: 104 TFLOP/s, at c = 2: 134).
+constexpr size_t kLdsPerCu = 160 * 1024;
+inline int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+// *t_out: modelled duration of the launch in units of (one block alone on a CU at the full matrix rate)
+inline int pick_blocks_per_cu(long long nwg, int cmax, double *t_out = nullptr) {
+  static const int forced = getenv("HG_CONV_OCC") ? atoi(getenv("HG_CONV_OCC")) : 0;   // experiments: fixed cap
+  static const double e[9] = {0, 0.71, 0.85, 0.90, 0.92, 0.93, 0.93, 0.93, 0.93};
+  if (cmax > 8) cmax = 8;
+  const double cus = (double)num_cus();
+  int best = cmax;
+  double best_t = 1e300;
+  for (int c = cmax; c >= 1; --c) {
+    if (forced > 0 && c != (forced < cmax ? forced : cmax)) continue;
+    const long long per_round = (long long)cus * c;
+    const long long full = nwg / per_round, rem = nwg - full * per_round;
+    double t = (double)full * c / e[c];
+    if (rem > 0) {
+      int cr = (int)((rem + (long long)cus - 1) / (long long)cus);
+      if (full > 0) cr = 2 * cr < c ? 2 * cr : c;   // freed slots are refilled greedily: the tail lands unevenly
+      t += cr / e[cr];
+    }
+    if (t < best_t * 0.995) { best_t = t; best = c; }
+  }
+  if (t_out) *t_out = best_t;
+  return best;
+}
+
+// K split of a 128x128-tile launch with `nb` output tiles and `nch` K chunks: the split whose block count fills whole
+// rounds of the chip (256 tiles alone run at 0.71 of the matrix rate, 3 x 256 at 0.90), if that pays for the slab
+// traffic of k_splitk_reduce.  Times in seconds for `flops` and `out_bytes` of the whole launch.
+inline int pick_ksplit_128(long long nb, int nch, double flops, double out_bytes, int max_split = 16) {
+  int best = 1;
+  double best_t = 1e300;
+  for (int ks = 1; ks <= max_split && nch / ks >= 8; ++ks) {
+    double tm;
+    pick_blocks_per_cu(nb * ks, 3, &tm);
+    // tm blocks-alone-times, each block does 1/ks of the K loop of a (flops / nb) tile, on one of num_cus() CUs
+    double t = tm * (flops / nb / ks) / (157.3e12 / num_cus()) + 2e-6 * tm;   // + prologue / epilogue per block round
+    if (ks > 1) t += 8e-6 + (ks + 1) * out_bytes / 3e12;
+    if (t < best_t * 0.97) { best_t = t; best = ks; }
+  }
+  return best;
+}
+
 // Pick the largest tile that still gives >= ~1.5 blocks per CU.  Wide tiles need wide rows (the staging-register
 // bound R16 in k_conv): 256-pixel tiles Wc > 8, 128-pixel tiles Wc > 4.  Launches that cannot fill the chip with
 // output tiles (few pixels, many channels: the 2x2 ... 8x8 maps) split the reduction over K into slabs.
-ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool have_ws, bool big_split = true) {
+ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool have_ws, bool big_split = true, int taps = 9) {
   const long long pix = (long long)B * Hc * Wc;
   auto blocks = [&](int nb, int mb) { return ((N + nb - 1) / nb) * ((pix + mb - 1) / mb); };
   const bool wide256 = Wc > 8 && Hc > 8, wide128 = Wc > 4 && Hc > 4;
@@ -861,18 +956,14 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
   if (N <= 64 && wide256 && blocks(64, 256) >= 384) { p.tile = TILE_64x256; return p; }
   if (N > 64 && wide128) {
     const long long nb = blocks(128, 128);
-    if (nb >= 256) { p.tile = TILE_128x128; return p; }
-#if HG_CONV_BIGTILE_SPLITK
-    // few pixels, many channels (8x8 maps): keep the 128x128 tile (half the LDS operand reads per MFMA of the 64x64
-    // one) and get the blocks from a K split instead
     const int nch = (K + HG_CONV_KC - 1) / HG_CONV_KC;
-    if (big_split && have_ws && os == 1 && IS == 1 && nb >= 32 && nch >= 32) {
-      int ks = (int)((512 + nb - 1) / nb);
-      if (ks > nch / 8) ks = nch / 8;
-      if (ks > 16) ks = 16;
-      if (ks > 1) { p.tile = TILE_128x128; p.ksplit = ks; return p; }
+    const bool may_split = HG_CONV_BIGTILE_SPLITK && big_split && have_ws && os == 1 && IS == 1;
+    if (nb >= 256 || (may_split && nb >= 32 && nch >= 32)) {
+      p.tile = TILE_128x128;
+      if (may_split)
+        p.ksplit = pick_ksplit_128(nb, nch, 2.0 * pix * K * N * taps, (double)pix * N * 4);
+      return p;
     }
-#endif
   }
 #if HG_CONV_BIGTILE_SPLITK > 1
   // 4x4 maps (8 images per 128-pixel tile): the small-map instantiation of the 128x128 tile (larger halo bound)
@@ -906,43 +997,6 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
 }
 
 inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st);
-
-// How many blocks per CU should a launch of `nwg` equal blocks run with?  The MFMA kernels here are resident-block
-// bound: a CU with c blocks in flight sustains e[c] of the matrix peak (measured, tools/occ_probe.py: 0.71 / 0.85 / 0.90
-// for 1 / 2 / 3 blocks of the 128x128 tile), and a launch whose block count is not a multiple of (CUs x c) ends in a
-// round at low occupancy that the dispatcher also balances badly (1024 blocks at c = 3: 104 TFLOP/s, at c = 2: 134).
-constexpr size_t kLdsPerCu = 160 * 1024;
-inline int num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
-inline int pick_blocks_per_cu(long long nwg, int cmax) {
-  static const int forced = getenv("HG_CONV_OCC") ? atoi(getenv("HG_CONV_OCC")) : 0;   // experiments: fixed cap
-  if (forced > 0) return forced < cmax ? forced : cmax;
-  static const double e[9] = {0, 0.71, 0.85, 0.90, 0.92, 0.93, 0.93, 0.93, 0.93};
-  if (cmax > 8) cmax = 8;
-  const double cus = (double)num_cus();
-  int best = cmax;
-  double best_t = 1e300;
-  for (int c = cmax; c >= 1; --c) {
-    const long long per_round = (long long)cus * c;
-    const long long full = nwg / per_round, rem = nwg - full * per_round;
-    double t = (double)full * c / e[c];
-    if (rem > 0) {
-      int cr = (int)((rem + (long long)cus - 1) / (long long)cus);
-      if (full > 0) cr = 2 * cr < c ? 2 * cr : c;   // freed slots are refilled greedily: the tail lands unevenly
-      t += cr / e[cr];
-    }
-    if (t < best_t * 0.995) { best_t = t; best = c; }
-  }
-  return best;
-}
 
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM = false, int MT = 32>
 int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t st) {
@@ -1017,7 +1071,7 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
   constexpr int KC = IS == 2 ? 4 : HG_CONV_KC;
   a.slab = (float *)ws;
   if (force_ksplit > 0) return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, IS == 1>(a, tp, force_ksplit, false, st);
-  ConvPlan p = plan_conv(a.B, a.K, a.N, a.Hc, a.Wc, IS, a.os, ws != nullptr);
+  ConvPlan p = plan_conv(a.B, a.K, a.N, a.Hc, a.Wc, IS, a.os, ws != nullptr, true, TAPS);
   if (conv_ws_bytes(p, a.B, a.N, a.Ho, a.Wo) > ws_bytes) p.ksplit = 1;   // too little scratch: no K split
   switch (p.tile) {
     case TILE_16x256:   // 16 ch x 256 px on the 16x16x4 MFMA
@@ -1207,10 +1261,10 @@ size_t hg_conv2d_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t Hi, in
       const ConvPlan p = plan_conv(B, K, N, (Hi + 1) / 2, (Wi + 1) / 2, 1, 1, true, false);
       return p.tile == TILE_64x64 && p.ksplit > 1 ? (size_t)p.ksplit * B * N * Hi * Wi * sizeof(float) : 0;
     }
-    return conv_ws_bytes(plan_conv(B, K, N, Hi, Wi, 1, 1, true), B, N, Hi, Wi);
+    return conv_ws_bytes(plan_conv(B, K, N, Hi, Wi, 1, 1, true, true, ksize * ksize), B, N, Hi, Wi);
   }
   const int Ho = out_size(Hi, stride), Wo = out_size(Wi, stride);
-  return conv_ws_bytes(plan_conv(B, K, N, Ho, Wo, stride, 1, true), B, N, Ho, Wo);
+  return conv_ws_bytes(plan_conv(B, K, N, Ho, Wo, stride, 1, true, true, ksize * ksize), B, N, Ho, Wo);
 }
 
 int hg_conv_pack_weights_both(const float *w, float *wt_fwd, float *wt_dgrad, int32_t Co, int32_t Ci, int32_t ksize,
@@ -1344,6 +1398,8 @@ int hg_conv2d_wgrad(const float *in, const float *gout, float *gw, const float *
   if (!fits_i32(B, K, N, Hi, Wi)) return HG_EUNSUPPORTED;
   const WgradPlan p = make_wgrad_plan(B, K, N, Hi, Wi, ksize, stride);
   if (workspace_bytes < p.slab_bytes) return HG_EWORKSPACE;
+  // k_wgrad addresses one image's channels with 32-bit byte offsets below kFar
+  if ((long long)K * Hi * Wi >= (1LL << 29) || (long long)N * Hi * Wi >= (1LL << 29)) return HG_EUNSUPPORTED;
   WgradArgs a;
   a.in = in; a.gout = gout; a.slab = (float *)workspace; a.iscale = iscale; a.gscale = gscale;
   a.B = B; a.K = K; a.N = N; a.Hi = Hi; a.Wi = Wi; a.Ho = out_size(Hi, stride); a.Wo = out_size(Wi, stride);
