@@ -132,6 +132,91 @@ __global__ __launch_bounds__(256, 2) void kc(const Args a) {
   a.out[blockIdx.x * 256 + tid] = s;
 }
 
+
+// double-buffered LDS: chunk c+1 is written to the other buffer before the MFMAs of chunk c, one barrier per chunk
+__global__ __launch_bounds__(256, 2) void kd(const Args a) {
+  __shared__ float lds[2 * (WS + XS) + 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 31, lk = lane >> 5, wc = wave & 1, wp = wave >> 1;
+  for (int i = tid; i < 2 * (WS + XS); i += 256) lds[i] = a.in[i % (WS + XS)];
+  __syncthreads();
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int aoff = lk * 128 + wc * 64 + lm;
+  int pixoff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = (wp * 2 + j) * 32 + lm;
+    pixoff[j] = (p >> 5) * 34 + (p & 31) + lk * 832;
+  }
+  float xr[4];
+  f32x4 wr[5];
+  const float *base = a.in + (size_t)(blockIdx.x & 63) * 65536;
+  auto prefetch = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[i] = base[(c & 7) * a.stride + tid + i * 256];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wr[i] = *reinterpret_cast<const f32x4 *>(base + 16384 + (c & 7) * a.stride + (tid + i * 256) * 4);
+  };
+  auto stage = [&](int buf) __attribute__((always_inline)) {
+    float *Ws = lds + buf * (WS + XS), *Xs = Ws + WS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (tid + i * 256 < XS) Xs[tid + i * 256] = xr[i];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (tid + i * 256 < WS / 4) reinterpret_cast<f32x4 *>(Ws)[tid + i * 256] = wr[i];
+  };
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const float *Ws = lds + buf * (WS + XS), *Xs = Ws + WS;
+    float av[2][2], bv[2][2];
+    auto ldop = [&](int s, int slot) __attribute__((always_inline)) {
+      const int t = s / 2, kk = s % 2;
+      const int toff = a.toff[t];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[slot][i] = Ws[(t * 4 + kk * 2) * 128 + aoff + i * 32];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[slot][j] = Xs[pixoff[j] + toff + kk * 2 * 832];
+    };
+    ldop(0, 0);
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+      if (s + 1 < 18) ldop(s + 1, (s + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
+    }
+  };
+  prefetch(0);
+  stage(0);
+  prefetch(1);
+  __syncthreads();
+  for (int c = 0; c < a.nchunks; c += 2) {
+    stage(1);              // chunk c+1 -> buffer 1 (its readers finished before the last barrier)
+    prefetch(c + 2);
+    compute(0);
+    __syncthreads();
+    stage(0);
+    prefetch(c + 3);
+    compute(1);
+    __syncthreads();
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  a.out[blockIdx.x * 256 + tid] = s;
+}
+
 template <int OPS, int BAR, int STAGE>
 void run(Args a, int grid, const char *what) {
   hipEvent_t e0, e1;
@@ -178,6 +263,12 @@ int main(int argc, char **argv) {
     run<2, 1, 0>(a, grid, "wide LDS operands, 2 barriers");
     run<2, 1, 1>(a, grid, "wide LDS operands, 2 barriers, staging");
     run<0, 0, 0>(a, grid, "registers, no barrier");
+    {
+      hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); float ms = 0;
+      for (int rep = 0; rep < 3; ++rep) { (void)hipEventRecord(e0); hipLaunchKernelGGL(kd, dim3(grid), dim3(256), 0, 0, a); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); }
+      const double flop = (double)grid * 4 * a.nchunks * 72 * 4096.0;
+      printf("%-58s grid %4d: %7.3f ms  %6.1f TFLOP/s (%.3f of 157.3)\n", "LDS operands, staging, DOUBLE-BUFFERED, 1 barrier", grid, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3);
+    }
   }
   return 0;
 }
