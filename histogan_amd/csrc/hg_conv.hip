@@ -1073,6 +1073,21 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
   if (force_ksplit > 0) return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, IS == 1>(a, tp, force_ksplit, false, st);
   ConvPlan p = plan_conv(a.B, a.K, a.N, a.Hc, a.Wc, IS, a.os, ws != nullptr, true, TAPS);
   if (conv_ws_bytes(p, a.B, a.N, a.Ho, a.Wo) > ws_bytes) p.ksplit = 1;   // too little scratch: no K split
+  // 3x3 stride-1 launches also exist with 2-channel K chunks: 16 fewer staging registers = one more block per CU (4
+  // instead of 3).  Taken when that makes the launch whole rounds (1024 / 2048 blocks: 134 -> 139 TFLOP/s) and for the
+  // 32-channel tile (+2..5 %); deep-K layers lose 3 % to the doubled barrier count and keep the 4-channel chunks.
+  if constexpr (TAPS == 9 && IS == 1 && KC == 4) {
+    const long long px = (long long)a.B * a.Hc * a.Wc, cus = num_cus();
+    if (p.tile == TILE_32x256) return launch_conv<1, 4, 1, 2, TAPS, 2, IS>(a, tp, 1, true, st);
+    if (p.tile == TILE_64x256 || (p.tile == TILE_128x128 && p.ksplit == 1)) {
+      const int nbt = p.tile == TILE_64x256 ? 64 : 128, mbt = p.tile == TILE_64x256 ? 256 : 128;
+      const long long nwg = ((a.N + nbt - 1) / nbt) * ((px + mbt - 1) / mbt);
+      if (nwg % (4 * cus) == 0 && nwg % (3 * cus) != 0 && nwg <= 32 * cus) {
+        if (p.tile == TILE_64x256) return launch_conv<1, 4, 2, 2, TAPS, 2, IS>(a, tp, 1, true, st);
+        return launch_conv<2, 2, 2, 2, TAPS, 2, IS>(a, tp, 1, true, st);
+      }
+    }
+  }
   switch (p.tile) {
     case TILE_16x256:   // 16 ch x 256 px on the 16x16x4 MFMA
       return launch_conv<1, 4, 1, 4, TAPS, 4, IS, false, 16>(a, tp, 1, true, st);
