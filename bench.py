@@ -103,10 +103,10 @@ G_LAYERS = [(64, 2048, 4), (2048, 2048, 4), (2048, 1024, 8), (1024, 1024, 8), (1
 
 def recorded_traffic(key):
     """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes of exactly this
-    launch (profiles/r01_conv_pmc.md); None when no measurement is recorded for it."""
+    launch (profiles/r02_pmc_traffic.json 'bench', tools/conv_traffic.sh); None when no measurement is recorded for it."""
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')) as f:
-            rec = json.load(f)[key]
+        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')) as f:
+            rec = json.load(f)['bench'][key]
         return rec['fetch_bytes'] + rec['write_bytes']
     except Exception:
         return None
@@ -495,7 +495,7 @@ def main():
                 'bound': 'mfma', 'achieved': fl / tf / 1e12, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': fl / tf / 1e12 / FP32_PEAK_TFLOPS,
                 'traffic': recorded_traffic('k_conv_fwd_256_128_64_b32') if args.batch == 32 else None,
-                'traffic_unit': 'bytes/launch (FETCH_SIZE + WRITE_SIZE, profiles/r01_conv_pmc.md)',
+                'traffic_unit': 'bytes/launch (FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_traffic.json)',
                 'launch_ms': tf * 1e3, 'flops_per_launch': fl,
                 'algorithmic_bytes_per_launch': 4.0 * (args.batch * 256 * 64 * 64 + args.batch * 128 * 64 * 64 + 9 * 256 * 128),
                 'wgrad': {'kernel': 'k_wgrad (hg_conv2d_wgrad), same layer', 'achieved': fl / tw / 1e12,

@@ -87,3 +87,18 @@ print(f'{len(gaps) / n:.0f} idle gaps per step; gaps > 20 us: {sum(1 for g in ga
       f'{sum(g[0] for g in gaps if g[0] > 20000) / 1e6 / n:.2f} ms/step; <= 20 us: {sum(g[0] for g in gaps if g[0] <= 20000) / 1e6 / n:.2f} ms/step')
 for g in sorted(gaps, key=lambda g: -g[0])[:24]:
     print(f'  {g[0] / 1e3:8.1f} us at +{g[3] / 1e6:8.2f} ms  after {sh(g[1])}  before {sh(g[2])}')
+
+# the longest stretches without a matrix-pipe kernel, with what ran inside them
+nomf = []
+prev_end = t0
+for s_, e_ in merged:
+    if s_ > prev_end: nomf.append((prev_end, s_))
+    prev_end = max(prev_end, e_)
+print(f'{len(nomf) / n:.0f} stretches without a matrix kernel per step; the longest:')
+other = sorted((s_, e_, nme) for s_, e_, nme in win if not MFMA.search(nme))
+for a_, b_ in sorted(nomf, key=lambda iv: iv[0] - iv[1])[:int(sys.argv[5]) if len(sys.argv) > 5 else 16]:
+    inside = [(min(e_, b_) - max(s_, a_), nme) for s_, e_, nme in other if s_ < b_ and e_ > a_]
+    agg = {}
+    for d_, nme in inside: agg[sh(nme)] = agg.get(sh(nme), 0) + d_
+    top = ', '.join(f'{k} {v / 1e3:.0f}us' for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:4])
+    print(f'  {(b_ - a_) / 1e3:7.1f} us at +{(a_ - t0) / 1e6:7.2f} ms: {top}')
