@@ -465,7 +465,9 @@ struct CGeom {
 // 12 waves per 2x2-tile block).  The 9-tap tile leaves room for ONE wave per SIMD (144 accumulators + staging), so every
 // s_waitcnt / barrier / staging instruction of that wave idles the matrix pipe (measured MFMA utilisation 0.62); with
 // three lighter waves per SIMD another wave's MFMAs fill those gaps.
-template <int WN, int WK, int WS, int TAPS, int PC, int LTW, int IS, int MT, int TS = 1>
+// SC: operand scales (iscale / gscale of the fused modulated-convolution backward) -- its own instantiation: the scale
+// lookups cost the unscaled kernel 190 spilled SGPRs (v_readlane / v_writelane in the chunk loop) when they shared one.
+template <int WN, int WK, int WS, int TAPS, int PC, int LTW, int IS, int MT, int TS = 1, bool SC = false>
 __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a) {
   typedef MfmaTile<MT> M;
   static_assert(TS == 1 || (TS == 3 && TAPS == 9), "tap split: rows of the 3x3 kernel");
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a
       const int gx = x0 + gpx, gy = y0 + gpy;
       const bool ok = gy < Ho && gx < Wo;
       unsigned off = ok ? (unsigned)(gcs * HWo + gy * Wo + gx) * 4u : kFar;
-      gmask = ok ? gstat : 0u;
+      if constexpr (SC) gmask = ok ? gstat : 0u;
       const unsigned gstep = (unsigned)(GCPI * HWo) * 4u;
 #pragma unroll
       for (int i = 0; i < NGI; ++i) {
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a
       const int hgy = y0 * IS + hy - PAD, hgx = x0 * IS + hx - PAD;
       const bool hok = hlane && (unsigned)hgy < (unsigned)Hi && (unsigned)hgx < (unsigned)Wi;
       unsigned hoff = hok ? (unsigned)(hcs * HWi + hgy * Wi + hgx) * 4u : kFar;
-      hmask = hok ? hstat : 0ull;
+      if constexpr (SC) hmask = hok ? hstat : 0ull;
       const unsigned hstep = (unsigned)(HCPI * HWi) * 4u;
 #pragma unroll
       for (int i = 0; i < NHI; ++i) {
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a
   constexpr int NBUF = ((WS == 1 || (TS > 1 && HG_WGRAD_TS_DBUF)) && 2 * BUFSZ * 4 <= 160 * 1024) ? 2 : 1;
   auto store = [&](int buf) __attribute__((always_inline)) {
     float *G2 = smem + buf * BUFSZ, *X2 = G2 + NBW * GP;
-    if (a.gscale == nullptr && a.iscale == nullptr) {
+    if constexpr (!SC) {
       // the training hot path: registers straight to LDS (invalid positions were loaded as 0.0); only the last pass of
       // each operand can address a channel row outside the block tile
 #pragma unroll
@@ -1165,7 +1167,8 @@ int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
     const size_t need = (size_t)WN * WK * 32 * WG_TP * sizeof(float);
     if (need > lds) lds = need;
   }
-  auto kern = k_wgrad<WN, WK, WS, TAPS, PC, LTW, IS, MT, TS>;
+  const bool sc = a.iscale != nullptr || a.gscale != nullptr;
+  auto kern = sc ? k_wgrad<WN, WK, WS, TAPS, PC, LTW, IS, MT, TS, true> : k_wgrad<WN, WK, WS, TAPS, PC, LTW, IS, MT, TS, false>;
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
