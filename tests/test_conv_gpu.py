@@ -23,6 +23,12 @@ CASES = [
     (16, 132, 500, 8, 8, 3), (16, 256, 260, 8, 8, 3), (6, 192, 640, 12, 12, 3),
     # 4x4 maps, many channels: the small-map instantiation of the 128x128 tile (8 images per pixel tile) + K split
     (64, 132, 1000, 4, 4, 3), (40, 520, 136, 4, 4, 3),
+    # block counts that select the per-launch variants on a 256-CU chip (hg_conv.hip dispatch_conv / pick_ksplit_128):
+    # 1024 blocks of the 128x128 tile and of the 64x256 tile -> the 2-channel K-chunk kernels at 4 blocks per CU (forward;
+    # the data gradients of these layers take the 16- / 32-channel tiles); 256 blocks with a deep K -> K split 3 (768 blocks)
+    (8, 8, 128, 128, 128, 3), (4, 8, 64, 256, 256, 3), (8, 128, 128, 64, 64, 3),
+    # 1024 blocks of the 1x1 128x128 tile (3 blocks per CU by registers = 1.33 rounds): LDS-padded to 2 per CU
+    (8, 16, 128, 128, 128, 1),
 ]
 
 
