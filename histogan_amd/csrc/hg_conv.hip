@@ -1000,6 +1000,23 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
 
 inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st);
 
+// output blocks of a plan over B x Hc x Wc compute pixels (before the K split)
+inline long long plan_blocks(const ConvPlan &p, int B, int N, int Hc, int Wc) {
+  const long long px = (long long)B * Hc * Wc;
+  const int nbt = p.tile == TILE_16x256 ? 16 : p.tile == TILE_32x256 ? 32 : (p.tile == TILE_64x256 || p.tile == TILE_64x64) ? 64 : 128;
+  const int mbt = (p.tile == TILE_128x128 || p.tile == TILE_128x128_SM) ? 128 : p.tile == TILE_64x64 ? 64 : 256;
+  return ((N + nbt - 1) / nbt) * ((px + mbt - 1) / mbt);
+}
+// 3x3 stride-1 launches: the 2-channel K-chunk kernels instead of the 4-channel ones?  (see dispatch_conv)
+inline bool short_k_chunks(const ConvPlan &p, int B, int N, int Hc, int Wc) {
+  if (p.tile == TILE_32x256) return true;
+  if (p.tile == TILE_64x256 || (p.tile == TILE_128x128 && p.ksplit == 1)) {
+    const long long nwg = plan_blocks(p, B, N, Hc, Wc), cus = num_cus();
+    return nwg % (4 * cus) == 0 && nwg % (3 * cus) != 0 && nwg <= 32 * cus;
+  }
+  return false;
+}
+
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM = false, int MT = 32>
 int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t st) {
   constexpr int NB = WC * TC * MT, MB = WP * TP * MT, NT = WC * WP * 64;
@@ -1079,15 +1096,10 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
   // instead of 3).  Taken when that makes the launch whole rounds (1024 / 2048 blocks: 134 -> 139 TFLOP/s) and for the
   // 32-channel tile (+2..5 %); deep-K layers lose 3 % to the doubled barrier count and keep the 4-channel chunks.
   if constexpr (TAPS == 9 && IS == 1 && KC == 4) {
-    const long long px = (long long)a.B * a.Hc * a.Wc, cus = num_cus();
-    if (p.tile == TILE_32x256) return launch_conv<1, 4, 1, 2, TAPS, 2, IS>(a, tp, 1, true, st);
-    if (p.tile == TILE_64x256 || (p.tile == TILE_128x128 && p.ksplit == 1)) {
-      const int nbt = p.tile == TILE_64x256 ? 64 : 128, mbt = p.tile == TILE_64x256 ? 256 : 128;
-      const long long nwg = ((a.N + nbt - 1) / nbt) * ((px + mbt - 1) / mbt);
-      if (nwg % (4 * cus) == 0 && nwg % (3 * cus) != 0 && nwg <= 32 * cus) {
-        if (p.tile == TILE_64x256) return launch_conv<1, 4, 2, 2, TAPS, 2, IS>(a, tp, 1, true, st);
-        return launch_conv<2, 2, 2, 2, TAPS, 2, IS>(a, tp, 1, true, st);
-      }
+    if (short_k_chunks(p, a.B, a.N, a.Hc, a.Wc)) {
+      if (p.tile == TILE_32x256) return launch_conv<1, 4, 1, 2, TAPS, 2, IS>(a, tp, 1, true, st);
+      if (p.tile == TILE_64x256) return launch_conv<1, 4, 2, 2, TAPS, 2, IS>(a, tp, 1, true, st);
+      return launch_conv<2, 2, 2, 2, TAPS, 2, IS>(a, tp, 1, true, st);
     }
   }
   switch (p.tile) {
@@ -1283,6 +1295,23 @@ size_t hg_conv2d_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t Hi, in
   }
   const int Ho = out_size(Hi, stride), Wo = out_size(Wi, stride);
   return conv_ws_bytes(plan_conv(B, K, N, Ho, Wo, stride, 1, true, true, ksize * ksize), B, N, Ho, Wo);
+}
+
+int hg_conv2d_plan(int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride, int32_t dgrad,
+                   int32_t out[5]) {
+  if (!out || !conv_args_ok(B, K, N, Hi, Wi, ksize, stride)) return HG_EINVAL;
+  if (dgrad && stride != 1) return HG_EUNSUPPORTED;   // four parity-class launches: no single plan
+  const int Hc = dgrad ? Hi : out_size(Hi, stride), Wc = dgrad ? Wi : out_size(Wi, stride);
+  const ConvPlan p = plan_conv(B, K, N, Hc, Wc, dgrad ? 1 : stride, 1, true, true, ksize * ksize);
+  const bool k2 = ksize == 3 && stride == 1 && HG_CONV_KC == 4 && short_k_chunks(p, B, N, Hc, Wc);
+  const int base_kc = (dgrad ? 1 : stride) == 2 ? 4 : HG_CONV_KC;
+  out[0] = (int32_t)p.tile;
+  out[1] = p.ksplit;
+  out[2] = p.tile == TILE_16x256 ? 4 : (p.tile == TILE_64x64 ? 2 * base_kc : (k2 ? 2 : base_kc));
+  const long long nb = plan_blocks(p, B, N, Hc, Wc) * p.ksplit;
+  out[3] = nb > 0x7fffffffLL ? 0x7fffffff : (int32_t)nb;
+  out[4] = num_cus();
+  return HG_OK;
 }
 
 int hg_conv_pack_weights_both(const float *w, float *wt_fwd, float *wt_dgrad, int32_t Co, int32_t Ci, int32_t ksize,

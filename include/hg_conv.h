@@ -64,6 +64,15 @@ int hg_modconv2d_fwd(const float *in, const float *wt, float *out, const float *
 size_t hg_conv2d_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
                                  int32_t stride, int32_t dgrad);
 
+/* The launch plan hg_conv2d_fwd (dgrad = 0) / the stride-1 hg_conv2d_dgrad (dgrad = 1) take for these arguments (host logic
+ * only, no device work; with no GPU present 256 CUs are assumed):
+ *   out[0] tile (0: 16 ch x 256 px, 1: 32 x 256, 2: 64 x 256, 3: 128 x 128, 4: 128 x 128 small-map, 5: 64 x 64),
+ *   out[1] K split, out[2] input channels per K chunk, out[3] blocks of the launch, out[4] CUs planned for.
+ * The block count decides the K split and the chunk size: a launch should be a whole number of rounds of
+ * (CUs x blocks per CU) -- DESIGN.md section 8. */
+int hg_conv2d_plan(int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride, int32_t dgrad,
+                   int32_t out[5]);
+
 /* Data gradient of that convolution:  gin (B,N,Hi,Wi) <- gout (B,K,Ho,Wo), K = the convolution's OUTPUT
  * channels, N = its INPUT channels, (Hi,Wi) = the size of the convolution's input; wt packed with
  * HG_CONV_PACK_DGRAD.   gin[b,n] = oscale[b,n] * sum_k dgrad(iscale[b,k] * gout[b,k]).

@@ -103,3 +103,38 @@ def test_pack_cache_registration_is_additive_and_weak():
     assert C._registered_owner(fake, ka) is None and ka not in C._cacheable     # dead owner: dropped on lookup
     C.enable_pack_cache(None)
     assert not C._cacheable
+
+
+def test_conv_launch_plan_fills_whole_rounds(L):
+    """hg_conv2d_plan (host logic of hg_conv.hip: plan_conv / pick_ksplit_128 / short_k_chunks): the generator's layers at
+    the benchmark shape (256^2, capacity 16, batch 32) get block counts that are whole rounds of (CUs x blocks per CU) --
+    DESIGN.md section 8: 1024 blocks -> the 2-channel K-chunk kernels (4 blocks per CU), 256-block launches with a deep
+    K -> K split 3 (768 blocks = 3 per CU), the 32-channel tile always on 2-channel chunks."""
+    import ctypes
+
+    def plan(B, K, N, S, k=3, stride=1, dgrad=0):
+        out = (ctypes.c_int32 * 5)()
+        assert L.lib.hg_conv2d_plan(B, K, N, S, S, k, stride, dgrad, out) == 0
+        return dict(tile=out[0], ksplit=out[1], kc=out[2], blocks=out[3], cus=out[4])
+
+    if plan(32, 256, 128, 64)['cus'] != 256:
+        pytest.skip('plan expectations are written for the 256 CUs of an MI355X')
+    T16, T32, T64W, T128, T128SM, T64 = range(6)
+    p = plan(32, 256, 128, 64)                       # bench.py's roofline launch
+    assert (p['tile'], p['ksplit'], p['kc'], p['blocks']) == (T128, 1, 2, 1024)
+    p = plan(32, 1024, 512, 16)                      # 256 output tiles, 256 K chunks
+    assert (p['tile'], p['ksplit'], p['blocks']) == (T128, 3, 768) and p['kc'] == 4
+    p = plan(32, 512, 256, 32)                       # 512 blocks = 2 per CU: nothing to gain from a split
+    assert (p['tile'], p['ksplit'], p['kc'], p['blocks']) == (T128, 1, 4, 512)
+    p = plan(32, 128, 64, 128)                       # 64 ch x 256 px tile, 2048 blocks
+    assert (p['tile'], p['kc'], p['blocks']) == (T64W, 2, 2048)
+    assert plan(32, 64, 32, 256)['tile'] == T32 and plan(32, 64, 32, 256)['kc'] == 2
+    assert plan(64, 16, 16, 256)['tile'] == T16      # first discriminator block: the 16x16x4 MFMA tile
+    p = plan(32, 2048, 1024, 8)                      # 8x8 maps: 128 output tiles, split to whole rounds
+    assert p['tile'] == T128 and p['ksplit'] > 1 and p['blocks'] % 256 == 0
+    assert plan(32, 2048, 2048, 4)['tile'] == T128SM
+    # the data gradient is planned as the convolution with the channel roles swapped
+    assert plan(32, 128, 256, 64, dgrad=1) == plan(32, 128, 256, 64)
+    # validation
+    out = (ctypes.c_int32 * 5)()
+    assert L.lib.hg_conv2d_plan(0, 1, 1, 4, 4, 3, 1, 0, out) < 0 and L.lib.hg_conv2d_plan(1, 1, 1, 4, 4, 5, 1, 0, out) < 0
