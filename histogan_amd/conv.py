@@ -94,6 +94,7 @@ def enable_pack_cache(params=None):
     if params is None:
         _cache.clear()
         _cacheable.clear()
+        _multi.clear()
         return
     for p in params:
         if p.dim() == 4:
@@ -159,12 +160,63 @@ def pack_weights(w, mode):
         st = _stamp(w, owner)
         if hit is not None and hit[0] == st:
             return hit[1]
-        # a registered (training) weight needs both operands once per optimizer step: one read, two writes
+        # A registered (training) weight needs both operands once per optimizer step, and so do all its siblings in the
+        # same flat buffer: ONE launch packs every convolution weight of that buffer (hg_conv_pack_weights_multi) the
+        # first time one of them is asked for after the buffer changed.
+        if PACK_MULTI and _pack_owner(owner, w.device):
+            hit = _cache.get((key, mode))
+            if hit is not None and hit[0] == st:
+                return hit[1]
         both = _pack_both(w)
         for m in (PACK_FWD, PACK_DGRAD):
             _cache[(key, m)] = (st, both[m])
         return both[mode]
     return _pack_weights(w, mode)
+
+
+PACK_MULTI = os.environ.get('HG_PACK_MULTI', '1') != '0'
+_multi = {}          # owner -> dict(sig, keys, bufs, table, n, blocks): the batched-pack plan of one flat buffer
+
+
+class _PackItem(ctypes.Structure):       # include/hg_conv.h: hg_pack_item
+    _fields_ = [('w', ctypes.c_void_p), ('wt_fwd', ctypes.c_void_p), ('wt_dgrad', ctypes.c_void_p),
+                ('Co', ctypes.c_int32), ('Ci', ctypes.c_int32), ('ksize', ctypes.c_int32), ('block_begin', ctypes.c_int32)]
+
+
+def _pack_owner(owner, device):
+    """Pack every live registered weight of flat buffer `owner` with one launch into persistent operand buffers and
+    stamp their cache entries.  The plan (buffers + device descriptor table) is rebuilt when the set of weights changes."""
+    live = []
+    for key, (own, ref) in list(_cacheable.items()):
+        p = ref()
+        if own == owner and p is not None and p.data_ptr() == key[0] and p.is_cuda and p.device == device \
+                and p.dtype == torch.float32 and p.is_contiguous() and p.shape[2] == p.shape[3] and p.shape[2] in (1, 3):
+            live.append((key, p))
+    if not live:
+        return False
+    sig = tuple(k for k, _ in live)
+    plan = _multi.get(owner)
+    with on_device(device):
+        if plan is None or plan['sig'] != sig:
+            items = (_PackItem * len(live))()
+            bufs, blocks = {}, 0
+            for i, (key, p) in enumerate(live):
+                Co, Ci, k, _ = p.shape
+                wf = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_FWD), dtype=torch.float32, device=device)
+                wd = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_DGRAD), dtype=torch.float32, device=device)
+                bufs[key] = (wf, wd)
+                items[i] = _PackItem(p.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, blocks)
+                blocks += lib.hg_conv_pack_blocks(Co, Ci)
+            raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).clone()
+            plan = _multi[owner] = dict(sig=sig, bufs=bufs, table=raw.to(device), n=len(live), blocks=blocks)
+        check(lib.hg_conv_pack_weights_multi(plan['table'].data_ptr(), plan['n'], plan['blocks'], raw_stream(device)),
+              'hg_conv_pack_weights_multi')
+    for key, p in live:
+        st = _stamp(p, owner)
+        wf, wd = plan['bufs'][key]
+        _cache[(key, PACK_FWD)] = (st, wf)
+        _cache[(key, PACK_DGRAD)] = (st, wd)
+    return True
 
 
 def pack_b6(w, mode):

@@ -800,12 +800,14 @@ __global__ __launch_bounds__(256) void k_pack(const float *__restrict__ w, float
 
 // both packings from ONE read of the weights (the training step needs the forward and the data-gradient operand of
 // every convolution once per optimizer step)
+// one 32 (co) x 32 (ci) x TAPS tile of both packed operands; `tile_mem`: 32 * (32 * TAPS + 1) floats of LDS
 template <int TAPS>
-__global__ __launch_bounds__(256) void k_pack_both(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wd,
-                                                   int Co, int Ci, int Kpf, int Npf, int Kpd, int Npd) {
+__device__ __forceinline__ void pack_both_tile(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wd,
+                                               int Co, int Ci, int Kpf, int Npf, int Kpd, int Npd, int bx, int by,
+                                               float *tile_mem) {
   constexpr int RW = 32 * TAPS;
-  __shared__ float tile[32][RW + 1];
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  float(*tile)[RW + 1] = reinterpret_cast<float(*)[RW + 1]>(tile_mem);
+  const int ci0 = bx * 32, co0 = by * 32;
   if (co0 >= Co || ci0 >= Ci) {   // padding-only tile: zeros, no loads
     for (int e = threadIdx.x; e < 32 * RW; e += 256) {
       const int b = e & 31, a_ = (e >> 5) & 31, t = e >> 10;
@@ -840,6 +842,28 @@ __global__ __launch_bounds__(256) void k_pack_both(const float *__restrict__ w, 
       if (kk < Kpd && nn < Npd) wd[((size_t)t * Kpd + kk) * Npd + nn] = tile[a_][b * TAPS + (TAPS - 1 - t)];
     }
   }
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void k_pack_both(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wd,
+                                                   int Co, int Ci, int Kpf, int Npf, int Kpd, int Npd) {
+  __shared__ float tile_mem[32 * (32 * TAPS + 1)];
+  pack_both_tile<TAPS>(w, wf, wd, Co, Ci, Kpf, Npf, Kpd, Npd, blockIdx.x, blockIdx.y, tile_mem);
+}
+
+// Every convolution weight of a model in ONE launch (hg_conv_pack_weights_multi): block -> (item, tile) through the items'
+// first-block table.  ~50 launches of 6-80 us per optimizer step become two.
+__global__ __launch_bounds__(256) void k_pack_multi(const hg_pack_item *__restrict__ items, int n_items) {
+  __shared__ float tile_mem[32 * (32 * 9 + 1)];
+  int it = 0;
+  while (it + 1 < n_items && (int)blockIdx.x >= items[it + 1].block_begin) ++it;   // wave-uniform scan (n_items ~ 30)
+  const hg_pack_item im = items[it];
+  const int local = (int)blockIdx.x - im.block_begin;
+  const int Kpf = (im.Ci + 15) / 16 * 16, Npf = (im.Co + 127) / 128 * 128, Kpd = (im.Co + 15) / 16 * 16, Npd = (im.Ci + 127) / 128 * 128;
+  const int gx = Npd / 32;
+  const int bx = local % gx, by = local / gx;
+  if (im.ksize == 3) pack_both_tile<9>(im.w, im.wt_fwd, im.wt_dgrad, im.Co, im.Ci, Kpf, Npf, Kpd, Npd, bx, by, tile_mem);
+  else pack_both_tile<1>(im.w, im.wt_fwd, im.wt_dgrad, im.Co, im.Ci, Kpf, Npf, Kpd, Npd, bx, by, tile_mem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1295,6 +1319,18 @@ size_t hg_conv2d_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t Hi, in
   }
   const int Ho = out_size(Hi, stride), Wo = out_size(Wi, stride);
   return conv_ws_bytes(plan_conv(B, K, N, Ho, Wo, stride, 1, true, true, ksize * ksize), B, N, Ho, Wo);
+}
+
+int32_t hg_conv_pack_blocks(int32_t Co, int32_t Ci) {
+  if (Co <= 0 || Ci <= 0) return 0;
+  return (round_up(Ci, 128) / 32) * (round_up(Co, 128) / 32);
+}
+
+int hg_conv_pack_weights_multi(const hg_pack_item *items_dev, int32_t n_items, int32_t total_blocks, void *stream) {
+  if (!items_dev || n_items <= 0 || total_blocks <= 0) return HG_EINVAL;
+  hipLaunchKernelGGL(k_pack_multi, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, items_dev, n_items);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
 }
 
 int hg_conv2d_plan(int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride, int32_t dgrad,

@@ -64,6 +64,18 @@ int hg_modconv2d_fwd(const float *in, const float *wt, float *out, const float *
 size_t hg_conv2d_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
                                  int32_t stride, int32_t dgrad);
 
+/* Both packed operands of MANY weights in one launch (a model's convolution weights after an optimizer step: ~50
+ * launches of hg_conv_pack_weights_both become one per flat buffer).  `items_dev`: device array of n_items descriptors,
+ * block_begin = running sum of hg_conv_pack_blocks(Co, Ci) over the preceding items (first = 0); total_blocks = the
+ * sum over all items.  ksize 1 or 3; wt_fwd / wt_dgrad sized by hg_conv_packed_elems as for the single call. */
+typedef struct hg_pack_item {
+  const float *w;
+  float *wt_fwd, *wt_dgrad;
+  int32_t Co, Ci, ksize, block_begin;
+} hg_pack_item;
+int32_t hg_conv_pack_blocks(int32_t Co, int32_t Ci);
+int hg_conv_pack_weights_multi(const hg_pack_item *items_dev, int32_t n_items, int32_t total_blocks, void *stream);
+
 /* The launch plan hg_conv2d_fwd (dgrad = 0) / the stride-1 hg_conv2d_dgrad (dgrad = 1) take for these arguments (host logic
  * only, no device work; with no GPU present 256 CUs are assumed):
  *   out[0] tile (0: 16 ch x 256 px, 1: 32 x 256, 2: 64 x 256, 3: 128 x 128, 4: 128 x 128 small-map, 5: 64 x 64),
