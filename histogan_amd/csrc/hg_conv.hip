@@ -135,7 +135,8 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
   // Upper bound (in 1/16 per pixel) of the halo size over the geometries the host builds for this tile shape:
   // 256-pixel tiles are only used with rows >= 16 wide (32x8 / 16x16: <= 1.33), 128-pixel tiles with rows >= 8
   // wide (<= 1.6), 64-pixel tiles with anything down to 4x4 (2.25) or, with SM, 2x2 maps (4.0); stride 2: 5.08.
-  constexpr int R16 = IS == 2 ? 83 : (TAPS == 1 ? 16 : (SM ? 64 : (MB == 256 ? 22 : (MB == 128 ? 26 : 36))));
+  // (stride 2 with SM: 2x2 output tiles, a 5x5 halo per 4 pixels = 6.25)
+  constexpr int R16 = IS == 2 ? (SM ? 100 : 83) : (TAPS == 1 ? 16 : (SM ? 64 : (MB == 256 ? 22 : (MB == 128 ? 26 : 36))));
   constexpr int HMAX = KC * MB * R16 / 16;
   constexpr int NH = (HMAX + NT - 1) / NT;
 
@@ -1007,14 +1008,18 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
 #endif
   p.tile = TILE_64x64;
   // pixel tiles of the 64x64 shape: images are grouped when the map is smaller than the tile
-  const int tw = Wc <= 2 && IS == 1 ? 2 : (Wc <= 4 ? 4 : (Wc <= 8 ? 8 : (Wc <= 16 ? 16 : 32)));
-  int th = Hc <= 2 && IS == 1 ? 2 : (Hc <= 4 ? 4 : (Hc <= 8 ? 8 : (Hc <= 16 ? 16 : 32)));
+  const int tw = Wc <= 2 ? 2 : (Wc <= 4 ? 4 : (Wc <= 8 ? 8 : (Wc <= 16 ? 16 : 32)));
+  int th = Hc <= 2 ? 2 : (Hc <= 4 ? 4 : (Hc <= 8 ? 8 : (Hc <= 16 ? 16 : 32)));
   if (th > 64 / tw) th = 64 / tw;
   const int ni = 64 / (tw * th);
   const long long nblk = (long long)((Wc + tw - 1) / tw) * ((Hc + th - 1) / th) * ((B + ni - 1) / ni) * ((N + 63) / 64);
   const int kc = IS == 2 ? 8 : 2 * HG_CONV_KC, nchunks = (K + kc - 1) / kc;
+  // blocks to aim for: 1024 for the stride-1 launches (2x2 maps, 2048 channels: 103 -> 113 TFLOP/s; the kernel is small enough
+  // for 4+ blocks per CU), 512 for the stride-2 forward and the four parity-class launches of the stride-2 data gradient
+  // (measured slower with more, shorter blocks)
+  const int tgt64 = (big_split && IS == 1) ? 1024 : 512;
   if (have_ws && os == 1 && nblk < 384 && nchunks >= 8) {
-    int ks = (int)((512 + nblk - 1) / nblk);
+    int ks = (int)((tgt64 + nblk - 1) / nblk);
     if (ks > nchunks / 4) ks = nchunks / 4;
     if (ks > 32) ks = 32;
     if (ks > 1) p.ksplit = ks;
@@ -1113,7 +1118,7 @@ template <int TAPS, int IS>
 int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStream_t st, int force_ksplit = 0) {
   constexpr int KC = IS == 2 ? 4 : HG_CONV_KC;
   a.slab = (float *)ws;
-  if (force_ksplit > 0) return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, IS == 1>(a, tp, force_ksplit, false, st);
+  if (force_ksplit > 0) return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, true>(a, tp, force_ksplit, false, st);
   ConvPlan p = plan_conv(a.B, a.K, a.N, a.Hc, a.Wc, IS, a.os, ws != nullptr, true, TAPS);
   if (conv_ws_bytes(p, a.B, a.N, a.Ho, a.Wo) > ws_bytes) p.ksplit = 1;   // too little scratch: no K split
   // 3x3 stride-1 launches also exist with 2-channel K chunks: 16 fewer staging registers = one more block per CU (4
@@ -1135,7 +1140,7 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
     case TILE_128x128_SM:
       if constexpr (IS == 1) return launch_conv<2, 2, 2, 2, TAPS, KC, IS, true>(a, tp, p.ksplit, true, st);
       else return HG_EUNSUPPORTED;
-    default: return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, IS == 1>(a, tp, p.ksplit, true, st);
+    default: return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, true>(a, tp, p.ksplit, true, st);
   }
 }
 
