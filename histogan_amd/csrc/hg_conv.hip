@@ -122,7 +122,7 @@ struct MfmaTile<16> {
 // FE (fused extras) = input scale / output scale / noise / LeakyReLU support; the plain instantiation (bias only)
 // keeps ~90 fewer registers and is what the training hot path runs.
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM, int MT, bool FE>
-__global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvArgs a) {
+__device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, const int bidy, const int bidz) {
   typedef MfmaTile<MT> M;
   constexpr int KS = M::KS;         // channels per MFMA
   static_assert(KC % KS == 0, "chunk must hold whole MFMA k-steps");
@@ -150,13 +150,13 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
   const int wc = wave % WC, wp = wave / WC;
   const int Hi = a.Hi, Wi = a.Wi, K = a.K, N = a.N;
 
-  int pt = blockIdx.x;
+  int pt = bidx;
   const int tx = pt % g.tiles_x;
   pt /= g.tiles_x;
   const int ty = pt % g.tiles_y;
   const int grp = pt / g.tiles_y;
   const int x0 = tx << g.lTW, y0 = ty << g.lTH, b0 = grp << g.lNI;
-  const int n0 = blockIdx.y * NB;
+  const int n0 = bidy * NB;
   const int TWm = (1 << g.lTW) - 1, THm = (1 << g.lTH) - 1;
 
   // ---- staging descriptors of the halo tile (chunk-invariant): byte offset of the element against this block's first
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
   f32x4 wr[NW];
   const int nchunks_all = (K + KC - 1) / KC;
   const int cps = (nchunks_all + a.ksplit - 1) / a.ksplit;   // chunks per K split
-  const int c_begin = blockIdx.z * cps;
+  const int c_begin = bidz * cps;
   const int nchunks = c_begin + cps < nchunks_all ? c_begin + cps : nchunks_all;
   const int HWi = Hi * Wi;
   const float *inblk = a.in + (size_t)b0 * K * HWi;          // first image of this block (wave-uniform)
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
       const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
       if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
       const size_t pofs = ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
-      float *ob = (fin ? a.out : a.slab + (size_t)blockIdx.z * a.B * N * HWo) + pofs;
+      float *ob = (fin ? a.out : a.slab + (size_t)bidz * a.B * N * HWo) + pofs;
 #pragma unroll
       for (int i = 0; i < TC; ++i) {
 #pragma unroll
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
       const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
       if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
       const size_t pofs = ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
-      float *ob = (fin ? a.out : a.slab + (size_t)blockIdx.z * a.B * N * HWo) + pofs;
+      float *ob = (fin ? a.out : a.slab + (size_t)bidz * a.B * N * HWo) + pofs;
       const float nz = (a.noise_img != nullptr && fin)
                            ? a.noise_img[((size_t)b * a.noise_S + cy * a.os + a.oy) * a.noise_S + cx * a.os + a.ox] : 0.f;
       float posc[TC][M::NR];
@@ -411,6 +411,29 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
       }
     }
   }
+}
+
+
+template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM, int MT, bool FE>
+__global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvArgs a) {
+  conv_body<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, FE>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The stride-2 data gradient's four output-parity classes (1 / 2 / 2 / 4 taps: hg_conv2d_dgrad) as ONE launch: block
+// (4 t + c) is tile t of class c.  For the small maps of the discriminator's deep blocks the four launches were a few
+// dozen blocks and ~20 us each (launch latency, not work); one launch fills the chip four times better.
+struct ConvArgs4 {
+  ConvArgs c[4];
+  int tiles[4];    // pixel tiles (grid x extent) of each class
+};
+template <int WC, int WP, int TC, int TP, int KC, bool SM, int MT, bool FE>
+__global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv_parity4(const ConvArgs4 a) {
+  const int cls = blockIdx.x & 3, t = blockIdx.x >> 2;
+  if (t >= a.tiles[cls]) return;
+  if (cls == 0) conv_body<WC, WP, TC, TP, 1, KC, 1, SM, MT, FE>(a.c[0], t, blockIdx.y, blockIdx.z);
+  else if (cls == 1) conv_body<WC, WP, TC, TP, 2, KC, 1, SM, MT, FE>(a.c[1], t, blockIdx.y, blockIdx.z);
+  else if (cls == 2) conv_body<WC, WP, TC, TP, 2, KC, 1, SM, MT, FE>(a.c[2], t, blockIdx.y, blockIdx.z);
+  else conv_body<WC, WP, TC, TP, 4, KC, 1, SM, MT, FE>(a.c[3], t, blockIdx.y, blockIdx.z);
 }
 
 // out[b][n][p] = epilogue( sum_z slab[z][b][n][p] )   (fixed order: deterministic); epilogue as in k_conv
@@ -1046,9 +1069,10 @@ inline bool short_k_chunks(const ConvPlan &p, int B, int N, int Hc, int Wc) {
   return false;
 }
 
-template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM = false, int MT = 32>
-int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t st) {
-  constexpr int NB = WC * TC * MT, MB = WP * TP * MT, NT = WC * WP * 64;
+// geometry / tap tables of one launch into `a`; returns the dynamic LDS bytes (0: not addressable, see below)
+template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM, int MT>
+size_t prep_conv(ConvArgs &a, const Taps &tp, int ksplit) {
+  constexpr int NB = WC * TC * MT, MB = WP * TP * MT;
   int lo_y = 0, hi_y = 0, lo_x = 0, hi_x = 0;
   for (int t = 0; t < TAPS; ++t) {
     lo_y = tp.dy[t] < lo_y ? tp.dy[t] : lo_y; hi_y = tp.dy[t] > hi_y ? tp.dy[t] : hi_y;
@@ -1062,40 +1086,86 @@ int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t
   a.wrow_dx = tp.ntx > 1 ? (tp.w[1] - tp.w[0]) * a.Kp : 0;
   a.wrow_dy = TAPS > tp.ntx ? (tp.w[tp.ntx] - tp.w[0]) * a.Kp : 0;
   a.ksplit = ksplit;
-  // + dump rows for the spare staging lanes: 64 floats (halo) and, 16-byte aligned behind them, 64 float4 (weights)
-  size_t lds = ((size_t)TAPS * KC * NB + (size_t)KC * a.g.CHS + 64 + 8 + 256) * sizeof(float);
   // the halo loads address one block's images with 32-bit byte offsets
-  if ((long long)(1 << a.g.lNI) * a.K * a.Hi * a.Wi >= (1LL << 30)) return HG_EUNSUPPORTED;
-  const bool fe = a.iscale || a.oscale || a.noise_img || a.slope > 0.f;
-  auto kern = fe ? k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, true> : k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, false>;
-  // blocks per CU for THIS launch (see pick_blocks_per_cu): fewer than the registers allow when that makes the block
-  // count a whole number of rounds; enforced by asking for more LDS than 1/(c+1) of a CU's
-  static int cmax[2] = {0, 0};
-  if (!cmax[fe]) {
+  if ((long long)(1 << a.g.lNI) * a.K * a.Hi * a.Wi >= (1LL << 30)) return 0;
+  // + dump rows for the spare staging lanes: 64 floats (halo) and, 16-byte aligned behind them, 64 float4 (weights)
+  return ((size_t)TAPS * KC * NB + (size_t)KC * a.g.CHS + 64 + 8 + 256) * sizeof(float);
+}
+
+// blocks per CU for a launch of `nwg` blocks of `kern` (see pick_blocks_per_cu): fewer than the registers allow when that
+// makes the block count a whole number of rounds; enforced by asking for more LDS than 1/(c+1) of a CU's.  `state`: the
+// kernel's cached {register-limited blocks per CU, "large dynamic LDS allowed" flag}.
+inline int fit_blocks_per_cu(const void *kern, int threads, long long nwg, size_t &lds, int state[2], const char *what) {
+  if (!state[0]) {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)kern, NT, lds) != hipSuccess || n < 1) n = 1;
-    cmax[fe] = n;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, threads, lds) != hipSuccess || n < 1) n = 1;
+    state[0] = n;
   }
-  const long long nwg = (long long)a.g.tiles_x * a.g.tiles_y * a.g.groups * ((a.N + NB - 1) / NB) * ksplit;
-  const int by_lds = (int)(kLdsPerCu / lds), cm = by_lds < cmax[fe] ? (by_lds > 1 ? by_lds : 1) : cmax[fe];
+  const int by_lds = (int)(kLdsPerCu / lds), cm = by_lds < state[0] ? (by_lds > 1 ? by_lds : 1) : state[0];
   const int c = pick_blocks_per_cu(nwg, cm);
   if (c < cm) {
     const size_t need = (size_t)kLdsPerCu / (c + 1) + 512;
     if (lds < need) lds = need;
   }
   static const bool dbg = getenv("HG_CONV_DEBUG") != nullptr;
-  if (dbg) fprintf(stderr, "k_conv<%d,%d,%d,%d,taps %d,kc %d,is %d,mt %d,fe %d>: %lld blocks, max %d (registers %d) -> %d per CU, lds %zu\n",
-                   WC, WP, TC, TP, TAPS, KC, IS, MT, (int)fe, nwg, cm, cmax[fe], c, lds);
-  static bool big_lds[2] = {false, false};   // dynamic LDS above 48 KB has to be allowed once per kernel
-  if (lds > 48 * 1024 && !big_lds[fe]) {
-    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
+  if (dbg) fprintf(stderr, "%s: %lld blocks, max %d (registers %d) -> %d per CU, lds %zu\n", what, nwg, cm, state[0], c, lds);
+  if (lds > 48 * 1024 && !state[1]) {   // dynamic LDS above 48 KB has to be allowed once per kernel
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCu);
     if (e != hipSuccess) return (int)e;
-    big_lds[fe] = true;
+    state[1] = 1;
   }
+  return 0;
+}
+
+template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM = false, int MT = 32>
+int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t st) {
+  constexpr int NB = WC * TC * MT, NT = WC * WP * 64;
+  size_t lds = prep_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT>(a, tp, ksplit);
+  if (!lds) return HG_EUNSUPPORTED;
+  const bool fe = a.iscale || a.oscale || a.noise_img || a.slope > 0.f;
+  auto kern = fe ? k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, true> : k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, false>;
+  static int state[2][2] = {{0, 0}, {0, 0}};
+  const long long nwg = (long long)a.g.tiles_x * a.g.tiles_y * a.g.groups * ((a.N + NB - 1) / NB) * ksplit;
+  char what[96];
+  snprintf(what, sizeof what, "k_conv<%d,%d,%d,%d,taps %d,kc %d,is %d,mt %d,fe %d>", WC, WP, TC, TP, TAPS, KC, IS, MT, (int)fe);
+  if (int rc = fit_blocks_per_cu((const void *)kern, NT, nwg, lds, state[fe], what)) return rc;
   const dim3 grid((unsigned)(a.g.tiles_x * a.g.tiles_y * a.g.groups), (unsigned)((a.N + NB - 1) / NB), (unsigned)ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);
   HG_LAUNCH_CHECK();
   if (ksplit > 1 && reduce) return launch_splitk_reduce(a, ksplit, st);
+  return HG_OK;
+}
+
+// the four parity-class launches of a stride-2 data gradient as one (k_conv_parity4); the caller reduces the K-split slabs
+template <int WC, int WP, int TC, int TP, int KC, bool SM = false, int MT = 32>
+int launch_conv_parity4(const ConvArgs (&base)[4], const Taps (&tp)[4], int ksplit, hipStream_t st) {
+  constexpr int NB = WC * TC * MT, NT = WC * WP * 64;
+  ConvArgs4 a4;
+  size_t lds = 0;
+  long long tiles_sum = 0;
+  int tiles_max = 0;
+  for (int c = 0; c < 4; ++c) {
+    a4.c[c] = base[c];
+    a4.tiles[c] = 0;
+    if (base[c].Hc <= 0 || base[c].Wc <= 0) continue;   // empty class (1-pixel-wide image)
+    size_t l = c == 0 ? prep_conv<WC, WP, TC, TP, 1, KC, 1, SM, MT>(a4.c[c], tp[c], ksplit)
+               : c == 3 ? prep_conv<WC, WP, TC, TP, 4, KC, 1, SM, MT>(a4.c[c], tp[c], ksplit)
+                        : prep_conv<WC, WP, TC, TP, 2, KC, 1, SM, MT>(a4.c[c], tp[c], ksplit);
+    if (!l) return HG_EUNSUPPORTED;
+    lds = l > lds ? l : lds;
+    a4.tiles[c] = a4.c[c].g.tiles_x * a4.c[c].g.tiles_y * a4.c[c].g.groups;
+    tiles_sum += a4.tiles[c];
+    tiles_max = a4.tiles[c] > tiles_max ? a4.tiles[c] : tiles_max;
+  }
+  if (!tiles_max) return HG_OK;
+  const ConvArgs &a = base[0];
+  const bool fe = a.iscale || a.oscale || a.noise_img || a.slope > 0.f;
+  auto kern = fe ? k_conv_parity4<WC, WP, TC, TP, KC, SM, MT, true> : k_conv_parity4<WC, WP, TC, TP, KC, SM, MT, false>;
+  static int state[2][2] = {{0, 0}, {0, 0}};
+  const int ny = (a.N + NB - 1) / NB;
+  if (int rc = fit_blocks_per_cu((const void *)kern, NT, tiles_sum * ny * ksplit, lds, state[fe], "k_conv_parity4")) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(4 * tiles_max), (unsigned)ny, (unsigned)ksplit), dim3(NT), lds, st, a4);
+  HG_LAUNCH_CHECK();
   return HG_OK;
 }
 
@@ -1441,31 +1511,52 @@ int hg_conv2d_dgrad(const float *gout, const float *wt, float *gin, const float 
   a.os = 2;
   // K split decided once for the four parity launches (they fill disjoint pixels of the same slabs)
   int ksplit = 0;
+  bool plan64 = false;
   {
     ConvPlan p = plan_conv(B, K, N, (Hi + 1) / 2, (Wi + 1) / 2, 1, 1, workspace != nullptr, false);
+    plan64 = p.tile == TILE_64x64 && Hi > 1 && Wi > 1;
     // (a 1-pixel-wide image has empty parity classes, whose slab pixels would never be written: no split then)
     if (Hi > 1 && Wi > 1 && p.tile == TILE_64x64 && p.ksplit > 1 &&
         (size_t)p.ksplit * B * N * Hi * Wi * sizeof(float) <= workspace_bytes)
       ksplit = p.ksplit;
   }
+  ConvArgs ca[4];
+  Taps tps[4];
   for (int pY = 0; pY < 2; ++pY)
     for (int pX = 0; pX < 2; ++pX) {
-      a.Hc = (Hi - pY + 1) / 2; a.Wc = (Wi - pX + 1) / 2;
-      if (a.Hc <= 0 || a.Wc <= 0) continue;
-      a.oy = pY; a.ox = pX;
-      tp.n = 0; tp.ntx = pX ? 2 : 1;
+      ConvArgs &c = ca[pY * 2 + pX];
+      Taps &t = tps[pY * 2 + pX];
+      c = a;
+      c.Hc = (Hi - pY + 1) / 2; c.Wc = (Wi - pX + 1) / 2;
+      c.oy = pY; c.ox = pX;
+      t.n = 0; t.ntx = pX ? 2 : 1;
       for (int dy = 0; dy < 3; ++dy)
         for (int dx = 0; dx < 3; ++dx)
           if (((pY + 1 - dy) & 1) == 0 && ((pX + 1 - dx) & 1) == 0) {
-            tp.dy[tp.n] = (pY + 1 - dy) / 2; tp.dx[tp.n] = (pX + 1 - dx) / 2; tp.w[tp.n] = 8 - (3 * dy + dx);
-            ++tp.n;
+            t.dy[t.n] = (pY + 1 - dy) / 2; t.dx[t.n] = (pX + 1 - dx) / 2; t.w[t.n] = 8 - (3 * dy + dx);
+            ++t.n;
           }
+    }
+  static const bool merge4 = !(getenv("HG_DGRAD_S2_MERGE") && atoi(getenv("HG_DGRAD_S2_MERGE")) == 0);
+  if (merge4 && plan64) {
+    // small maps (the 64x64 tile): the four classes in one launch
+    // (one launch has the blocks of all four classes: half the K split planned per class fills the chip as well, with
+    // half the slab traffic -- measured best of 1 / 2 / 4)
+    static const int ksdiv = getenv("HG_DGRAD_S2_KSDIV") ? atoi(getenv("HG_DGRAD_S2_KSDIV")) : 2;
+    if (ksplit > 1) ksplit = ksplit / ksdiv > 1 ? ksplit / ksdiv : 1;
+    for (int c = 0; c < 4; ++c) ca[c].slab = (float *)workspace;
+    const int rc = launch_conv_parity4<2, 2, 1, 1, 2 * HG_CONV_KC, true>(ca, tps, ksplit > 1 ? ksplit : 1, st);
+    if (rc) return rc;
+  } else {
+    for (int c = 0; c < 4; ++c) {
+      if (ca[c].Hc <= 0 || ca[c].Wc <= 0) continue;
       int rc;
-      if (tp.n == 1) rc = dispatch_conv<1, 1>(a, tp, workspace, workspace_bytes, st, ksplit);
-      else if (tp.n == 2) rc = dispatch_conv<2, 1>(a, tp, workspace, workspace_bytes, st, ksplit);
-      else rc = dispatch_conv<4, 1>(a, tp, workspace, workspace_bytes, st, ksplit);
+      if (tps[c].n == 1) rc = dispatch_conv<1, 1>(ca[c], tps[c], workspace, workspace_bytes, st, ksplit);
+      else if (tps[c].n == 2) rc = dispatch_conv<2, 1>(ca[c], tps[c], workspace, workspace_bytes, st, ksplit);
+      else rc = dispatch_conv<4, 1>(ca[c], tps[c], workspace, workspace_bytes, st, ksplit);
       if (rc) return rc;
     }
+  }
   if (ksplit > 1) {
     a.slab = (float *)workspace;
     return launch_splitk_reduce(a, ksplit, st);
