@@ -50,19 +50,32 @@ __global__ __launch_bounds__(256, 2) void kc(const Args a) {
   f32x4 wr[5];
   const float *base = a.in + (size_t)(blockIdx.x & 63) * 65536;
   auto prefetch = [&](int c) __attribute__((always_inline)) {
+    if (STAGE & 4) return;
+    if (STAGE & 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xr[i] = base[(c & 7) * a.stride + tid + i * 256];
+      for (int i = 0; i < 4; ++i) xr[i] = base[(c & 7) * a.stride + tid + i * 256];
+    }
+    if (STAGE & 2) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) wr[i] = *reinterpret_cast<const f32x4 *>(base + 16384 + (c & 7) * a.stride + (tid + i * 256) * 4);
+      for (int i = 0; i < 5; ++i) wr[i] = *reinterpret_cast<const f32x4 *>(base + 16384 + (c & 7) * a.stride + (tid + i * 256) * 4);
+    }
   };
   float ra = a.in[tid], rb = a.in[tid + 256];
+  if (STAGE & 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[i] = ra + i;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) wr[i] = f32x4{ra, rb, ra + i, rb};
+  }
   for (int c = -1; c < a.nchunks; ++c) {
     if (c >= 0) {
       if (BAR) __syncthreads();
-      if (STAGE) {
+      if (STAGE & 5) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (tid + i * 256 < XS) Xs[tid + i * 256] = xr[i];
+      }
+      if (STAGE & 6) {
 #pragma unroll
         for (int i = 0; i < 5; ++i)
           if (tid + i * 256 < WS / 4) reinterpret_cast<f32x4 *>(Ws)[tid + i * 256] = wr[i];
@@ -217,6 +230,83 @@ __global__ __launch_bounds__(256, 2) void kd(const Args a) {
   a.out[blockIdx.x * 256 + tid] = s;
 }
 
+// LDS-DMA staging (global_load_lds / buffer_load ... lds), two LDS buffers, one barrier per chunk: chunk c+1 lands in the
+// other buffer while chunk c is multiplied; no staging registers, no ds_write
+__global__ __launch_bounds__(256, 2) void kg(const Args a) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * (WS + XS) + 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 31, lk = lane >> 5, wc = wave & 1, wp = wave >> 1;
+  for (int i = tid; i < 2 * (WS + XS); i += 256) lds[i] = a.in[i % (WS + XS)];
+  __syncthreads();
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int aoff = lk * 128 + wc * 64 + lm;
+  int pixoff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int p = (wp * 2 + j) * 32 + lm;
+    pixoff[j] = (p >> 5) * 34 + (p & 31) + lk * 832;
+  }
+  const float *base = a.in + (size_t)(blockIdx.x & 63) * 65536;
+  auto dma = [&](int c, int buf) __attribute__((always_inline)) {
+    float *Ws = lds + buf * (WS + XS), *Xs = Ws + WS;
+    const float *src = base + (c & 7) * a.stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i < 3 || tid < XS - 768) __builtin_amdgcn_global_load_lds(src + tid + i * 256, Xs + wave * 64 + i * 256, 4, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+      if (i < 4 || tid < WS / 4 - 1024) __builtin_amdgcn_global_load_lds(src + 16384 + (tid + i * 256) * 4, Ws + (wave * 64 + i * 256) * 4, 16, 0, 0);
+  };
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const float *Ws = lds + buf * (WS + XS), *Xs = Ws + WS;
+    float av[2][2], bv[2][2];
+    auto ldop = [&](int s, int slot) __attribute__((always_inline)) {
+      const int t = s / 2, kk = s % 2;
+      const int toff = a.toff[t];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[slot][i] = Ws[(t * 4 + kk * 2) * 128 + aoff + i * 32];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bv[slot][j] = Xs[pixoff[j] + toff + kk * 2 * 832];
+    };
+    ldop(0, 0);
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+      if (s + 1 < 18) ldop(s + 1, (s + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][i], bv[s & 1][j], acc[i][j], 0, 0, 0);
+    }
+  };
+  dma(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+  __syncthreads();
+  for (int c = 0; c < a.nchunks; c += 2) {
+    dma(c + 1, 1);
+    compute(0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    dma(c + 2, 0);
+    compute(1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+  a.out[blockIdx.x * 256 + tid] = s;
+}
+
 template <int OPS, int BAR, int STAGE>
 void run(Args a, int grid, const char *what) {
   hipEvent_t e0, e1;
@@ -259,15 +349,19 @@ int main(int argc, char **argv) {
     const int grid = 512;
     run<0, 0, 0>(a, grid, "registers, no barrier");
     run<1, 1, 0>(a, grid, "LDS operands, 2 barriers");
-    run<1, 1, 1>(a, grid, "LDS operands, 2 barriers, staging (= k_conv loop)");
-    run<2, 1, 0>(a, grid, "wide LDS operands, 2 barriers");
-    run<2, 1, 1>(a, grid, "wide LDS operands, 2 barriers, staging");
-    run<0, 0, 0>(a, grid, "registers, no barrier");
-    {
+    run<1, 1, 3>(a, grid, "  + staging: 4 dword + 5 dwordx4 loads, 9 ds_writes");
+    run<1, 1, 1>(a, grid, "  + only the 4 dword loads + 4 ds_write_b32");
+    run<1, 1, 2>(a, grid, "  + only the 5 dwordx4 loads + 5 ds_write_b128");
+    run<1, 1, 4>(a, grid, "  + only the 9 ds_writes (no global loads)");
+    for (int which = 0; which < 2; ++which) {
       hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); float ms = 0;
-      for (int rep = 0; rep < 3; ++rep) { (void)hipEventRecord(e0); hipLaunchKernelGGL(kd, dim3(grid), dim3(256), 0, 0, a); (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1); }
+      for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0);
+        if (which) hipLaunchKernelGGL(kg, dim3(grid), dim3(256), 0, 0, a); else hipLaunchKernelGGL(kd, dim3(grid), dim3(256), 0, 0, a);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1); (void)hipEventElapsedTime(&ms, e0, e1);
+      }
       const double flop = (double)grid * 4 * a.nchunks * 72 * 4096.0;
-      printf("%-58s grid %4d: %7.3f ms  %6.1f TFLOP/s (%.3f of 157.3)\n", "LDS operands, staging, DOUBLE-BUFFERED, 1 barrier", grid, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3);
+      printf("%-58s grid %4d: %7.3f ms  %6.1f TFLOP/s (%.3f of 157.3)\n", which ? "LDS-DMA staging (glds), 2 LDS buffers, 1 barrier" : "register staging, 2 LDS buffers, 1 barrier", grid, ms, flop / ms / 1e9, flop / ms / 1e9 / 157.3);
     }
   }
   return 0;
