@@ -183,7 +183,14 @@ class _PackItem(ctypes.Structure):       # include/hg_conv.h: hg_pack_item
                 ('Co', ctypes.c_int32), ('Ci', ctypes.c_int32), ('ksize', ctypes.c_int32), ('block_begin', ctypes.c_int32)]
 
 
-def _pack_owner(owner, device):
+def build_pack_plans(device):
+    """Build the batched-pack plans of every registered flat buffer now (allocations + one small host-to-device copy each),
+    e.g. before a hipGraph capture, inside which a plan cannot be built."""
+    for owner in {own for own, _ in _cacheable.values()}:
+        _pack_owner(owner, device, launch=False)
+
+
+def _pack_owner(owner, device, launch=True):
     """Pack every live registered weight of flat buffer `owner` with one launch into persistent operand buffers and
     stamp their cache entries.  The plan (buffers + device descriptor table) is rebuilt when the set of weights changes."""
     live = []
@@ -198,6 +205,8 @@ def _pack_owner(owner, device):
     plan = _multi.get(owner)
     with on_device(device):
         if plan is None or plan['sig'] != sig:
+            if torch.cuda.is_current_stream_capturing():
+                return False          # (the table upload is not capturable: per-weight launches for this capture)
             items = (_PackItem * len(live))()
             bufs, blocks = {}, 0
             for i, (key, p) in enumerate(live):
@@ -209,6 +218,8 @@ def _pack_owner(owner, device):
                 blocks += lib.hg_conv_pack_blocks(Co, Ci)
             raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).clone()
             plan = _multi[owner] = dict(sig=sig, bufs=bufs, table=raw.to(device), n=len(live), blocks=blocks)
+        if not launch:
+            return True
         check(lib.hg_conv_pack_weights_multi(plan['table'].data_ptr(), plan['n'], plan['blocks'], raw_stream(device)),
               'hg_conv_pack_weights_multi')
     for key, p in live:

@@ -441,6 +441,8 @@ class Trainer():
                 o.graph_mode = True
             graph = torch.cuda.CUDAGraph()
             try:
+                from .conv import build_pack_plans
+                build_pack_plans(self.device)
                 torch.cuda.synchronize()
                 pool = getattr(self, '_graph_pool', None)
                 with torch.cuda.graph(graph, pool=pool):
