@@ -46,6 +46,9 @@
 #ifndef HG_WGRAD_TAPSPLIT
 #define HG_WGRAD_TAPSPLIT 2   // k_wgrad: the three kernel rows of a tile on three waves (1: 2x2-tile blocks only, 2: all 3x3 tiles)
 #endif
+#ifndef HG_WGRAD_PC128
+#define HG_WGRAD_PC128 1   // 128-pixel chunks for the pixel-split 3x3 weight-gradient tiles (<= 32 channels on one side)
+#endif
 #ifndef HG_CONV_BIGTILE_SPLITK
 #define HG_CONV_BIGTILE_SPLITK 2   // 128x128 tile + K split for 8x8 maps (1) and 4x4 maps (2)
 #endif
@@ -1224,6 +1227,13 @@ struct WgradPlan {
 
 inline int out_size(int in, int stride) { return (in - 1) / stride + 1; }  // k = 3, pad 1 (or k = 1, pad 0, stride 1)
 
+// pixels per chunk of k_wgrad.  128 where the per-chunk overhead (staging pass, barrier) has the least MFMA work to hide
+// behind: the 16x16 tile (4x less work per pixel) and the pixel-split 32-channel tiles of the 3x3 kernel (each of the WS
+// waves of a tile only multiplies 1/WS of a chunk) -- on rows at least 8 / 16 wide, where the halo still fits one pass.
+constexpr int wgrad_chunk_pixels(int stride, int MT, int lTW, int WS, int taps) {
+  return stride == 2 ? 32 : ((MT == 16 && lTW >= 3) || (HG_WGRAD_PC128 && MT == 32 && WS > 1 && taps == 9 && lTW >= 4)) ? 128 : 64;
+}
+
 WgradPlan make_wgrad_plan(int B, int K, int N, int Hi, int Wi, int ksize, int stride) {
   WgradPlan p;
   const int Ho = out_size(Hi, stride), Wo = out_size(Wi, stride);
@@ -1234,12 +1244,6 @@ WgradPlan make_wgrad_plan(int B, int K, int N, int Hi, int Wi, int ksize, int st
   p.lTW = lTW;
   // pixels per chunk: the 16x16 tile does 4x less MFMA work per pixel, so it takes 128-pixel chunks where the halo of
   // 128 pixels still fits one staging pass (rows >= 8 wide)
-  p.PC = stride == 2 ? 32 : ((p.MT == 16 && lTW >= 3) ? 128 : 64);
-  const int TW = 1 << lTW, TH = (p.PC / TW) < TW ? (p.PC / TW) : TW, NI = p.PC / (TW * TH);
-  p.tiles_x = (Wo + TW - 1) / TW;
-  p.tiles_y = (Ho + TH - 1) / TH;
-  p.groups = (B + NI - 1) / NI;
-  p.nchunks = p.tiles_x * p.tiles_y * p.groups;
   if (p.MT == 16) {
     p.WN = p.WK = 1;
   } else if (stride == 2) {  // only two shapes are instantiated for stride 2
@@ -1249,6 +1253,12 @@ WgradPlan make_wgrad_plan(int B, int K, int N, int Hi, int Wi, int ksize, int st
     p.WK = K > 32 ? 2 : 1;
   }
   p.WS = 4 / (p.WN * p.WK);
+  p.PC = wgrad_chunk_pixels(stride, p.MT, lTW, p.WS, ksize * ksize);
+  const int TW = 1 << lTW, TH = (p.PC / TW) < TW ? (p.PC / TW) : TW, NI = p.PC / (TW * TH);
+  p.tiles_x = (Wo + TW - 1) / TW;
+  p.tiles_y = (Ho + TH - 1) / TH;
+  p.groups = (B + NI - 1) / NI;
+  p.nchunks = p.tiles_x * p.tiles_y * p.groups;
   p.ktiles = (K + p.WK * p.MT - 1) / (p.WK * p.MT);
   p.ntiles = (N + p.WN * p.MT - 1) / (p.WN * p.MT);
   const int tiles = p.ktiles * p.ntiles;
@@ -1270,7 +1280,7 @@ WgradPlan make_wgrad_plan(int B, int K, int N, int Hi, int Wi, int ksize, int st
 
 template <int WN, int WK, int WS, int TAPS, int LTW, int IS, int MT = 32, int TS = 1>
 int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
-  constexpr int PC = IS == 2 ? 32 : ((MT == 16 && LTW >= 3) ? 128 : 64);
+  constexpr int PC = wgrad_chunk_pixels(IS, MT, LTW, WS, TAPS);
   using G = CGeom<PC, LTW, TAPS == 9 ? 1 : 0, IS>;
   size_t lds = ((size_t)WN * MT * (PC + 1) + (size_t)WK * MT * G::CHS) * sizeof(float);
   if ((WS == 1 || (TS > 1 && HG_WGRAD_TS_DBUF)) && 2 * lds <= 160 * 1024) lds *= 2;   // double buffered (NBUF in k_wgrad)

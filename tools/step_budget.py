@@ -87,8 +87,15 @@ for grp in ('G', 'D'):
         print(f'  {grp} {p:5s}: {t*1e3:7.2f} ms  {f/t/1e12:6.1f} TFLOP/s')
 print(f'{"layer":10s} {"B":>3} {"K":>5} {"N":>5} {"S":>4} k s pass  | x/step {"ms each":>8} {"TF":>6} {"ms/step":>8} {"excess":>7}')
 rows.sort(key=lambda r: -(r['t'] * r['cnt'] - r['flops'] * r['cnt'] / a.target / 1e12))
-for r in rows[:45]:
+for r in rows[:int(__import__('os').environ.get('HG_BUDGET_ROWS', '45'))]:
     ms = r['t'] * r['cnt'] * 1e3
     ex = ms - r['flops'] * r['cnt'] / a.target / 1e12 * 1e3
     print(f'{r["tag"]:10s} {r["b"]:3d} {r["K"]:5d} {r["N"]:5d} {r["S"]:4d} {r["k"]} {r["s"]} {r["p"]:5s} | {r["cnt"]:5.2f} '
           f'{r["t"]*1e3:8.3f} {r["flops"]/r["t"]/1e12:6.1f} {ms:8.3f} {ex:7.3f}')
+
+blk = {}
+for r in rows:
+    k = r['tag'].split('.')[0]
+    b = blk.setdefault(k, [0.0, 0.0])
+    b[0] += r['t'] * r['cnt']; b[1] += r['flops'] * r['cnt']
+print('per block: ' + '  '.join(f'{k} {v[0]*1e3:.2f} ms {v[1]/v[0]/1e12:.0f} TF' for k, v in sorted(blk.items())))
