@@ -94,6 +94,14 @@ constexpr unsigned kOOB = 0xFFFFFFFFu;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, unsigned bytes = kOOB) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000);
 }
+// a wave-uniform pointer the compiler may have parked in vector registers, back in scalar ones (a buffer descriptor built
+// from vector registers gets every load wrapped in a readfirstlane "waterfall" loop: the iscale loads of the fused-extras
+// kernel were)
+__device__ __forceinline__ const float *uniform_ptr(const float *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const float *)(((unsigned long long)hi << 32) | lo);
+}
 constexpr unsigned kFar = 0x80000000u;   // an out-of-range offset that stays out of range when < 2 GB is added to it
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
@@ -239,7 +247,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, con
   const int nchunks = c_begin + cps < nchunks_all ? c_begin + cps : nchunks_all;
   const int HWi = Hi * Wi;
   const float *inblk = a.in + (size_t)b0 * K * HWi;          // first image of this block (wave-uniform)
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wt), rs = make_rsrc(FE && a.iscale ? a.iscale : a.wt);
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wt), rs = make_rsrc(uniform_ptr(FE && a.iscale ? a.iscale : a.wt));
 
   // All loads are unconditional (a `valid ? load : 0` select makes the compiler branch around every load and wait for
   // it at once: the global latency then runs in series with the MFMAs of the chunk).
