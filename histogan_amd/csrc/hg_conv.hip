@@ -297,11 +297,20 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, con
     float av[2][TC], bv[2][TP];
     auto ldop = [&](int s_, int slot) __attribute__((always_inline)) {
       const int t = s_ / (KC / KS), kk = s_ % (KC / KS);
-      const int toff = a.toff[t];
 #pragma unroll
       for (int i = 0; i < TC; ++i) av[slot][i] = Ws[(t * KC + kk * KS) * NB + aoff + i * MT];
+      if constexpr (TAPS == 9) {
+        // the 3x3 tap grid: the three taps of a kernel row are consecutive floats of the halo row -- one address per
+        // (pixel tile, kernel row, k step) with the column as the instruction's immediate offset (a third of the address
+        // registers of the general form below)
+        const int roff = a.toff[(t / 3) * 3];
 #pragma unroll
-      for (int j = 0; j < TP; ++j) bv[slot][j] = Xs[pixoff[j] + toff + kk * KS * g.CHS];
+        for (int j = 0; j < TP; ++j) bv[slot][j] = (Xs + pixoff[j] + roff + kk * KS * g.CHS)[t % 3];
+      } else {
+        const int toff = a.toff[t];
+#pragma unroll
+        for (int j = 0; j < TP; ++j) bv[slot][j] = Xs[pixoff[j] + toff + kk * KS * g.CHS];
+      }
     };
     ldop(0, 0);
     // pin the schedule: [operand reads of step s+1] [MFMAs of step s] (the compiler otherwise batches the pixel-operand
