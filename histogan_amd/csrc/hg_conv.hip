@@ -387,43 +387,42 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, con
       }
     }
   } else {
-    // per-channel epilogue parameters first (before any store: the compiler cannot hoist them past possibly
-    // aliasing stores itself)
-    float pbias[TC][M::NR], pnw[TC][M::NR];
+    // One channel tile at a time: its 2 x NR per-channel parameters are loaded before that tile's stores (the compiler
+    // cannot hoist loads past possibly aliasing stores itself), the demodulation scale per (pixel tile, channel).  Holding
+    // the parameters of ALL tiles at once made this epilogue the register peak of the kernel (238 VGPRs = 2 blocks per
+    // CU); now the K loop is, as in the plain instantiation.
+    const float *__restrict__ pbias_ = a.bias, *__restrict__ pnw_ = a.noise_w, *__restrict__ posc_ = a.oscale;
 #pragma unroll
-    for (int i = 0; i < TC; ++i)
+    for (int i = 0; i < TC; ++i) {
+      float pbias[M::NR], pnw[M::NR];
 #pragma unroll
       for (int r = 0; r < M::NR; ++r) {
         const int ch = n0 + (wc * TC + i) * MT + M::row(r, lk);
         const int cc = ch < N ? ch : N - 1;
-        pbias[i][r] = (fin && a.bias) ? a.bias[cc] : 0.f;
-        pnw[i][r] = (fin && a.noise_img) ? a.noise_w[cc] : 0.f;
+        pbias[r] = (fin && pbias_) ? pbias_[cc] : 0.f;
+        pnw[r] = (fin && a.noise_img) ? pnw_[cc] : 0.f;
       }
 #pragma unroll
-    for (int j = 0; j < TP; ++j) {
-      const int p = (wp * TP + j) * MT + lm;
-      const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
-      const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
-      if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
-      const size_t pofs = ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
-      float *ob = (fin ? a.out : a.slab + (size_t)bidz * a.B * N * HWo) + pofs;
-      const float nz = (a.noise_img != nullptr && fin)
-                           ? a.noise_img[((size_t)b * a.noise_S + cy * a.os + a.oy) * a.noise_S + cx * a.os + a.ox] : 0.f;
-      float posc[TC][M::NR];
-#pragma unroll
-      for (int i = 0; i < TC; ++i)
+      for (int j = 0; j < TP; ++j) {
+        const int p = (wp * TP + j) * MT + lm;
+        const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
+        const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
+        if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
+        const size_t pofs = ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
+        float *ob = (fin ? a.out : a.slab + (size_t)bidz * a.B * N * HWo) + pofs;
+        const float nz = (a.noise_img != nullptr && fin)
+                             ? a.noise_img[((size_t)b * a.noise_S + cy * a.os + a.oy) * a.noise_S + cx * a.os + a.ox] : 0.f;
+        float posc[M::NR];
 #pragma unroll
         for (int r = 0; r < M::NR; ++r) {
           const int ch = n0 + (wc * TC + i) * MT + M::row(r, lk);
-          posc[i][r] = (fin && a.oscale) ? a.oscale[b * N + (ch < N ? ch : N - 1)] : 1.f;
+          posc[r] = (fin && posc_) ? posc_[b * N + (ch < N ? ch : N - 1)] : 1.f;
         }
-#pragma unroll
-      for (int i = 0; i < TC; ++i) {
 #pragma unroll
         for (int r = 0; r < M::NR; ++r) {
           const int ch = n0 + (wc * TC + i) * MT + M::row(r, lk);
           if (ch < N) {
-            float v = fmaf(acc[i][j][r], posc[i][r], fmaf(pnw[i][r], nz, pbias[i][r]));
+            float v = fmaf(acc[i][j][r], posc[r], fmaf(pnw[r], nz, pbias[r]));
             if (fin && a.slope > 0.f) v = v > 0.f ? v : a.slope * v;
             ob[(size_t)ch * HWo] = v;
           }
@@ -432,7 +431,6 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, con
     }
   }
 }
-
 
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM, int MT, bool FE>
 __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvArgs a) {
@@ -1215,7 +1213,10 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
   // instead of 3).  Taken when that makes the launch whole rounds (1024 / 2048 blocks: 134 -> 139 TFLOP/s) and for the
   // 32-channel tile (+2..5 %); deep-K layers lose 3 % to the doubled barrier count and keep the 4-channel chunks.
   if constexpr (TAPS == 9 && IS == 1 && KC == 4) {
-    if (short_k_chunks(p, a.B, a.N, a.Hc, a.Wc)) {
+    // (the fused-extras instantiations of the two larger tiles fit 3 blocks per CU at either chunk size -- their epilogue
+    // is the register peak -- so they keep the 4-channel chunks)
+    const bool fe = a.iscale || a.oscale || a.noise_img || a.slope > 0.f;
+    if (short_k_chunks(p, a.B, a.N, a.Hc, a.Wc) && (!fe || p.tile == TILE_32x256)) {
       if (p.tile == TILE_32x256) return launch_conv<1, 4, 1, 2, TAPS, 2, IS>(a, tp, 1, true, st);
       if (p.tile == TILE_64x256) return launch_conv<1, 4, 2, 2, TAPS, 2, IS>(a, tp, 1, true, st);
       return launch_conv<2, 2, 2, 2, TAPS, 2, IS>(a, tp, 1, true, st);
