@@ -140,3 +140,19 @@ def test_conv_launch_plan_fills_whole_rounds(L):
     # validation
     out = (ctypes.c_int32 * 5)()
     assert L.lib.hg_conv2d_plan(0, 1, 1, 4, 4, 3, 1, 0, out) < 0 and L.lib.hg_conv2d_plan(1, 1, 1, 4, 4, 5, 1, 0, out) < 0
+
+
+def test_pack_multi_block_table_is_consistent(L):
+    """hg_conv_pack_blocks (the per-weight block count of hg_conv_pack_weights_multi's table) covers both padded operands of
+    hg_conv_packed_elems with 32 x 32 tiles, and the batched entry point validates its arguments before any launch."""
+    for Co, Ci in [(16, 3), (2048, 2048), (3, 512), (130, 70), (1, 1)]:
+        nb = L.lib.hg_conv_pack_blocks(Co, Ci)
+        up = lambda v, m: (v + m - 1) // m * m
+        assert nb == (up(Ci, 128) // 32) * (up(Co, 128) // 32)
+        for k in (1, 3):
+            # every element of both operands lies in one of the nb tiles (tile = 32 co x 32 ci x k*k)
+            assert L.lib.hg_conv_packed_elems(Co, Ci, k, 0) <= nb * 32 * 32 * k * k
+            assert L.lib.hg_conv_packed_elems(Co, Ci, k, 1) <= nb * 32 * 32 * k * k
+    assert L.lib.hg_conv_pack_blocks(0, 4) == 0
+    assert L.lib.hg_conv_pack_weights_multi(None, 1, 1, None) < 0
+    assert L.lib.hg_conv_pack_weights_multi(1, 0, 1, None) < 0
