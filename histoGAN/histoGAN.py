@@ -2,6 +2,7 @@
 (`from histoGAN import Trainer, NanException`, histoGAN.py:18 of the reference's CLI; the other names
 are imported by ReHistoGAN/rehistoGAN.py:34 and the projection scripts).  Implementation:
 histogan_amd/{nets,trainer,optim,ddp}.py over the HIP kernels of histogan_amd/csrc/."""
+from histogan_amd.augment import AugWrapper
 from histogan_amd.nets import (Conv2DMod, Discriminator, DiscriminatorBlock, Generator, GeneratorBlock,
                                HistVectorizer, RGBBlock, StyleVectorizer)
 from histogan_amd.trainer import (EMA, HistoGAN, NanException, Trainer, evaluate_in_chunks, gradient_penalty,
@@ -9,4 +10,4 @@ from histogan_amd.trainer import (EMA, HistoGAN, NanException, Trainer, evaluate
 
 __all__ = ['Trainer', 'HistoGAN', 'NanException', 'Generator', 'GeneratorBlock', 'HistVectorizer', 'RGBBlock',
            'Conv2DMod', 'Discriminator', 'DiscriminatorBlock', 'StyleVectorizer', 'EMA', 'gradient_penalty',
-           'latent_to_w', 'styles_def_to_tensor', 'evaluate_in_chunks']
+           'latent_to_w', 'styles_def_to_tensor', 'evaluate_in_chunks', 'AugWrapper']

@@ -18,6 +18,7 @@ HG_PROJ = {'rgbuv': 0, 'rgchroma': 1, 'direct': 2}
 class HgHistParams(ctypes.Structure):
     """struct hg_hist_params (include/hg_hist.h)."""
     _fields_ = [
+        ('struct_size', ctypes.c_uint32),
         ('B', ctypes.c_int32), ('C', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
         ('stride_b', ctypes.c_int64), ('stride_c', ctypes.c_int64),
         ('stride_h', ctypes.c_int64), ('stride_w', ctypes.c_int64),
@@ -52,6 +53,8 @@ def _load():
     lib.hg_error_string.argtypes = [ctypes.c_int]
     lib.hg_rgbuv_hist_workspace_bytes.restype = ctypes.c_int
     lib.hg_rgbuv_hist_workspace_bytes.argtypes = [PP, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.hg_rgbuv_hist_uses_proj_cache.restype = ctypes.c_int
+    lib.hg_rgbuv_hist_uses_proj_cache.argtypes = [PP]
     lib.hg_rgbuv_hist_fwd.restype = ctypes.c_int
     lib.hg_rgbuv_hist_fwd.argtypes = [PP, vp, vp, vp, vp, sz, vp]
     lib.hg_rgbuv_hist_bwd.restype = ctypes.c_int
@@ -142,7 +145,7 @@ def _load():
 lib = _load()
 
 # every symbol include/hg_hist.h, hg_nets.h, hg_conv.h, hg_recolor.h and hg_augment.h declare
-EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_fwd',
+EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_uses_proj_cache', 'hg_rgbuv_hist_fwd',
            'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd', 'hg_selftest_fastlog',
            'hg_modulate_fwd', 'hg_modulate_bwd', 'hg_demod_noise_lrelu_fwd', 'hg_demod_noise_lrelu_bwd',
            'hg_diffgrad_step', 'hg_diffgrad_step_size', 'hg_diffgrad_step_dev', 'hg_ema_update', 'hg_nets_workspace_bytes', 'hg_channel_sum',

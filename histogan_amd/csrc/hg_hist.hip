@@ -30,7 +30,7 @@
 #include "../../include/hg_hist.h"
 #include <cstdlib>
 
-#define HG_VERSION_NUM 101
+#define HG_VERSION_NUM 102   // 102: hg_hist_params.struct_size (ABI guard), hg_rgbuv_hist_uses_proj_cache
 
 #ifndef HG_FWD_SCHED_GROUPS
 #define HG_FWD_SCHED_GROUPS 1
@@ -1770,6 +1770,9 @@ struct Plan {
 
 int validate(const hg_hist_params *p) {
   if (!p) return HG_EINVAL;
+  if (p->struct_size != sizeof(hg_hist_params)) return HG_EINVAL;   // stale header / unzeroed struct (include/hg_hist.h)
+  if (p->pre_relu != 0 && p->pre_relu != 1) return HG_EINVAL;
+  if (p->proj_cache && ((uintptr_t)p->proj_cache & 15)) return HG_EINVAL;
   if (p->B <= 0 || p->C < 3 || p->H <= 0 || p->W <= 0 || p->Hs <= 0 || p->Ws <= 0 || p->h <= 0) return HG_EINVAL;
   if (p->method < 0 || p->method > 2) return HG_EMETHOD;
   if (p->resize_mode < 0 || p->resize_mode > 2) return HG_ERESIZE;
@@ -1997,6 +2000,12 @@ int launch_bwd_planes(const DevParams &d, const Plan &pl, const float *x, const 
 extern "C" {
 
 int hg_version(void) { return HG_VERSION_NUM; }
+
+int hg_rgbuv_hist_uses_proj_cache(const hg_hist_params *p) {
+  const int rc = validate(p);
+  if (rc) return rc;
+  return sparse_path(p) ? 0 : 1;
+}
 
 const char *hg_error_string(int code) {
   switch (code) {

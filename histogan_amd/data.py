@@ -51,11 +51,16 @@ def _load_rgb(path, size=None, flip=False, rgba=False, crop_seed=None):
     img = Image.open(path).convert('RGBA' if rgba else 'RGB')    # convert_rgb_to_transparent / _transparent_to_rgb
     if size is not None:
         w, h = img.size
-        s = size / min(w, h)                                   # transforms.Resize(size): short side -> size
-        img = img.resize((max(size, round(w * s)), max(size, round(h * s))), Image.BILINEAR)
+        # transforms.Resize(size) (after resize_to_minimum_size, which is the same call for small images, :246-249): short
+        # side -> size, long side int(size * long / short) -- torchvision TRUNCATES -- and no-op when the short side matches
+        short, long = (w, h) if w <= h else (h, w)
+        if short != size:
+            new_long = int(size * long / short)
+            img = img.resize((size, new_long) if w <= h else (new_long, size), Image.BILINEAR)
         w, h = img.size
         if crop_seed is None:
-            l, t = (w - size) // 2, (h - size) // 2            # transforms.CenterCrop(size)
+            # transforms.CenterCrop(size): torchvision's offsets are int(round((dim - size) / 2.0)) (round half to even)
+            l, t = int(round((w - size) / 2.0)), int(round((h - size) / 2.0))
             img = img.crop((l, t, l + size, t + size))
         else:
             l, t, cw, ch = _random_resized_crop_box(w, h, np.random.RandomState(crop_seed))

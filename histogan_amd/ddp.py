@@ -15,8 +15,15 @@ import torch
 import torch.distributed as dist
 
 
+import os
+
+# HG_DIST_FORCE=1: take the data-parallel code paths (broadcasts, gradient / statistics / Hellinger all-reduces) whenever
+# a process group exists, even at world size 1 -- lets a 1-GPU box run the whole step through RCCL (tests/test_bench_gpu.py)
+FORCE = os.environ.get('HG_DIST_FORCE', '0') == '1'
+
+
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
 
 
 def world_size():
@@ -40,6 +47,12 @@ def broadcast_buffers(module, src=0):
             dist.broadcast(b.data, src)
 
 
+def _avg_in_collective():
+    """RCCL averages inside the collective (ReduceOp.AVG: no separate pass over the 364 + 399 MB gradient buffers);
+    gloo has no AVG, there the buffer is pre-scaled and summed (CPU tests, two-ranks-on-one-GPU tests)."""
+    return dist.get_backend() == 'nccl'
+
+
 class GradAllReduce:
     """Averaging all-reduce of a flat gradient buffer, optionally asynchronous."""
 
@@ -53,9 +66,13 @@ class GradAllReduce:
         if not is_dist():
             return
         g = self.flat.grad
-        g.mul_(1.0 / world_size())
+        if _avg_in_collective():
+            op = dist.ReduceOp.AVG
+        else:
+            op = dist.ReduceOp.SUM
+            g.mul_(1.0 / world_size())
         for c in g.chunk(self.chunks):
-            self._work.append(dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True))
+            self._work.append(dist.all_reduce(c, op=op, async_op=True))
 
     def finish(self):
         for w in self._work:

@@ -54,6 +54,7 @@ def _make_params(x, cfg, pre_relu=False):
                         f' inverse-quadratic. But the given value is {cfg.method}.')
     B, C, H, W = x.shape
     p = HgHistParams()
+    p.struct_size = ctypes.sizeof(HgHistParams)
     p.B, p.C, p.H, p.W = B, C, H, W
     p.stride_b, p.stride_c, p.stride_h, p.stride_w = x.stride()
     keep = []
@@ -107,9 +108,10 @@ class RGBuvHistFunction(torch.autograd.Function):
         fwd_b, _ = _ws_bytes(p)
         with on_device(x.device):
             # per-pixel projection cache for the backward (32 B per histogram pixel): only when a gradient will be asked
-            # for, only for the smooth kernels (the scatter paths re-classify pixels cheaply)
+            # for and only when the dense MFMA kernels will run (the scatter paths -- thresholding, narrow RBF --
+            # re-classify pixels cheaply and ignore it)
             cache = None
-            if ctx.needs_input_grad[0] and cfg.method != 'thresholding' and PROJ_CACHE:
+            if ctx.needs_input_grad[0] and PROJ_CACHE and lib.hg_rgbuv_hist_uses_proj_cache(ctypes.byref(p)) == 1:
                 cache = torch.empty((p.B, p.Hs * p.Ws, 8), dtype=torch.float32, device=x.device)
                 p.proj_cache = cache.data_ptr()
             ctx.cache = cache

@@ -433,25 +433,46 @@ class recoloringTrainer():
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def evaluate(self, num=0, image_batch=None, hist_batch=None, save_input=True, **unused):
-        """Recolour a batch with its target histograms and write `<num>-generated.jpg` [+ `<num>-input.jpg`].
-        (The reference's post-processing options -- pyramid upsampling, colour transfer, multi-histogram grids,
-        :1075-1180 -- are CPU/OpenCV code outside the hot path and are not offered.)"""
+    def evaluate(self, num=0, image_batch=None, hist_batch=None, triple_hist=False, double_hist=False, resizing=None,
+                 resizing_method=None, swapping_levels=1, pyramid_levels=5, level_blending=False, original_size=None,
+                 input_image_name=None, original_image=None, post_recoloring=False, save_input=True):
+        """Recolour a batch with its target histograms and write `<num>-generated.jpg` [+ `<num>-input.jpg`]: the
+        reference's parameter list (ReHistoGAN/rehistoGAN.py:1076-1081).  The device part (encoder-decoder + head, the
+        multi-histogram grids, the 'downscaling' resize of the written file) is implemented; the CPU / OpenCV / external
+        post-processing options -- `resizing='upscaling'` (BGU.exe or the Laplacian-pyramid swap of
+        utils/pyramid_upsampling.py) and `post_recoloring` (utils/color_transfer_MKL.py) -- are outside the hot path
+         and raise NotImplementedError when asked for."""
+        if resizing == 'upscaling' or post_recoloring:
+            raise NotImplementedError("recoloringTrainer.evaluate: resizing='upscaling' (BGU / pyramid) and post_recoloring "
+                                      'are CPU post-processing of the reference (utils/) outside the MI355X hot path')
         self.GAN.eval()
         if hist_batch is None or image_batch is None:
             batch = next(self.loader_evaluate)
             image_batch = batch['images'].to(self.device)
             hist_batch = batch['histograms'].to(self.device)
+            img_bt_sz = image_batch.shape[0]
+            extra = ['histograms2', 'histograms3'] if triple_hist is True else (['histograms2'] if double_hist is True else [])
+            if extra:               # the same images against two / three target histograms (:1089-1100)
+                image_batch = torch.cat([image_batch] * (len(extra) + 1), dim=0)
+                hist_batch = torch.cat([hist_batch] + [batch[k].to(self.device) for k in extra], dim=0)
+        else:
+            img_bt_sz = image_batch.shape[0]
         noise = self.rng.image_noise(hist_batch.shape[0], image_batch.shape[-1])
         generated_images = self._recolor(image_batch, hist_batch, noise)
         if num is not None and self.is_main:
             from .data import save_image_grid
             ext = 'jpg' if not self.transparent else 'png'
-            save_image_grid(generated_images, str(self.results_dir / self.name / f'{str(num)}-generated.{ext}'),
-                            nrow=image_batch.shape[0])
-            if save_input:
-                save_image_grid(image_batch, str(self.results_dir / self.name / f'{str(num)}-input.{ext}'),
-                                nrow=image_batch.shape[0])
+            multi = double_hist is True or triple_hist is True
+            num_rows = img_bt_sz if multi else int(np.ceil(np.sqrt(hist_batch.shape[0])))
+            output_name = str(self.results_dir / self.name / f'{str(num)}-generated.{ext}')
+            save_image_grid(generated_images, output_name, nrow=num_rows)
+            if resizing == 'downscaling' and original_size is not None:
+                from PIL import Image
+                Image.open(output_name).resize((original_size[0], original_size[1])).save(output_name)
+            if save_input is True:
+                save_image_grid(image_batch[:img_bt_sz] if multi else image_batch,
+                                str(self.results_dir / self.name / f'{str(num)}-input.{ext}'),
+                                nrow=img_bt_sz if multi else num_rows)
         return generated_images
 
     def print_log(self):

@@ -13,7 +13,18 @@ NaN recovery) -- restructured for the hardware:
 * the D phase runs the generator under no_grad (the reference builds and discards that graph, :904-910);
 * ONE device->host read-back per step (losses + NaN flag together) instead of >= 7 `.item()` syncs;
 * latents / noise drawn on the device (rng='device'); rng='reference' reproduces the reference's CPU
-  draws (`torch.randn(...).cuda()`, :166-189) for parity tests.
+  draws (`torch.randn(...).cuda()`, :166-189) for parity tests;
+* the read-back is DEFERRED by one step (`lazy_stats`): step n's statistics travel to pinned host memory
+  asynchronously and are looked at while step n+1 is already queued, so the GPU queue never drains at a step
+  boundary.  Reading `d_loss` / `g_loss` / `h_loss` / `last_gp_loss` / `q_loss` / `pl_mean` (or print_log, save,
+  evaluate) flushes what is pending first, so callers always see the values of the last finished step.
+
+Provenance: `_device_step`, `_graphed_step`, `train`, the statistics plumbing and the data sources are original.
+The API-compatibility shell -- `EMA`, `default`, `cast_list`, `is_empty`, `gradient_penalty`, `evaluate`,
+`generate_truncated`, `print_log`, `save` / `load` / `clear`, `model_name`, `init_folders`, `config` handling and the
+`Trainer.__init__` attribute block -- follows the reference method for method (histoGAN/histoGAN.py:107-163,
+718-851, 1022-1139, `.cuda()` -> `.to(self.device)`), because the reference CLI, its checkpoints and its scripts
+address exactly these names; none of it is on the timed path.
 """
 import json
 import os
@@ -47,6 +58,25 @@ G_OVERLAP = os.environ.get('HG_G_OVERLAP', '1') != '0'   # G-phase generator for
 GRAPH_MODE = os.environ.get('HG_GRAPH', 'auto')
 GRAPH_AUTO_RATIO = float(os.environ.get('HG_GRAPH_AUTO_RATIO', '0.6'))
 GRAPH_GP = os.environ.get('HG_GRAPH_GP', '1') != '0'      # gradient-penalty steps replay from their own graph too
+LAZY_STATS = os.environ.get('HG_LAZY_STATS', '1') != '0'  # statistics of step n read while step n+1 is queued (0: blocking read-back every step)
+
+
+def _lazy_field(name):
+    """A statistic the reference keeps as a plain attribute (`self.d_loss = ...`): reading it first flushes the deferred
+    read-backs, so the value is that of the last finished step."""
+    key = '_stat_' + name
+
+    def get(self):
+        if self.__dict__.get('_pending'):
+            self._drain(0, in_train=False)
+        try:
+            return self.__dict__[key]
+        except KeyError:
+            raise AttributeError(name) from None
+
+    def set_(self, v):
+        self.__dict__[key] = v
+    return property(get, set_)
 
 
 class NanException(Exception):
@@ -242,6 +272,9 @@ class SyntheticData:
 
 
 class Trainer():
+    d_loss, g_loss, h_loss = _lazy_field('d_loss'), _lazy_field('g_loss'), _lazy_field('h_loss')
+    last_gp_loss, q_loss, pl_mean = _lazy_field('last_gp_loss'), _lazy_field('q_loss'), _lazy_field('pl_mean')
+
     def __init__(self, name, results_dir, models_dir, image_size, network_capacity, transparent=False,
                  batch_size=4, mixed_prob=0.9, gradient_accumulate_every=1, lr=2e-4, num_workers=None,
                  save_every=1000, trunc_psi=0.6, fp16=False, fq_layers=[], fq_dict_size=256, attn_layers=[],
@@ -295,6 +328,11 @@ class Trainer():
         self.device = torch.device('cuda', torch.cuda.current_device())
         self.rng = _Rng(self.device, rng)
         self.graph_mode = GRAPH_MODE          # 'auto' | '1' | '0' | '2' (see GRAPH_MODE above)
+        self.lazy_stats = LAZY_STATS          # deferred read-back (module docstring); False: one blocking read-back per step
+        self.keep_step_events = False         # bench.py: keep one timing event per step (GPU-side per-step durations)
+        self.step_events = []
+        self._pending = []                    # [(event, pinned stats, meta)] of steps whose statistics were not read yet
+        self._nan_checkpoint = None           # NaN seen outside train(): the next train() call restores and raises
         self.is_main = ddp.rank() == 0
         self.run_evaluate = True      # benchmarks switch evaluate()/save() off (excluded from the metric)
         self.run_save = True
@@ -307,6 +345,7 @@ class Trainer():
         # the GAN, e.g. on NaN recovery); the next eligible step captures again
         for k in ('_graphs', '_graph', '_graph_pool', '_gs', '_gs_first'):
             self.__dict__.pop(k, None)
+        self.__dict__.setdefault('_pending', []).clear()
         args, kwargs = self.GAN_params
         self.GAN = HistoGAN(lr=self.lr, image_size=self.image_size, network_capacity=self.network_capacity,
                             transparent=self.transparent, fq_layers=self.fq_layers,
@@ -435,7 +474,10 @@ class Trainer():
                 o.graph_mode = False
             return stats
         graphs = self.__dict__.setdefault('_graphs', {})
-        if gp not in graphs:
+        # alpha (the Hellinger weight) and the batch size are host scalars baked into the captured launches: the cache is
+        # keyed on them, a call with another alpha captures its own graph instead of silently replaying the old value
+        key = (bool(gp), float(alpha), int(self.batch_size))
+        if key not in graphs:
             weights_changed()                  # every packed operand the step reads must be produced INSIDE the graph
             for o in (GAN.D_opt, GAN.G_opt):
                 o.graph_mode = True
@@ -455,16 +497,32 @@ class Trainer():
                 self._graph_failed = True
                 torch.cuda.synchronize()
                 print(f'hipGraph capture of the train step failed ({type(e).__name__}: {e}); running eagerly')
-                weights_changed()
+                self._reset_after_failed_step()
                 return self._device_step(alpha, gp, False, None)
             for o in (GAN.D_opt, GAN.G_opt):
                 o.graph_mode = False
-            graphs[gp] = (graph, stats)
+            graphs[key] = (graph, stats)
             self._graph = graph
-        graph, stats = graphs[gp]
+            if not getattr(self, '_graph_logged', False) and self.is_main:
+                self._graph_logged = True
+                print(f'train step: replaying captured hipGraphs (HG_GRAPH={self.graph_mode}; latent / noise draws follow '
+                      f'the static-input order -- for seed-reproducible runs pin HG_GRAPH=0 or 1)')
+        graph, stats = graphs[key]
         graph.replay()
         weights_changed()                      # eager steps in between must not trust operands packed by the graph
         return stats
+
+    def _reset_after_failed_step(self):
+        """State a partially executed `_device_step` can leave behind (an exception between the G phase's
+        `set_requires_grad(D, False)` and its restore, half-written flat gradient buffers): put everything back so that
+        the step can be run again from the top."""
+        GAN = self.GAN
+        set_requires_grad(GAN.D, True)
+        for o in (GAN.D_opt, GAN.G_opt):
+            o.zero_grad()
+            o.flat.direct_ok = False
+        GAN._reduce_d.finish()
+        weights_changed()
 
     def _device_step(self, alpha, apply_gradient_penalty, apply_path_penalty, gs=None):
         """All device work of one optimisation step (reference :853-989), no host synchronisation.  gs: static input
@@ -579,6 +637,21 @@ class Trainer():
         # The reference lets the G-phase backward deposit gradients in D as well and throws them away at the
         # next D_opt.zero_grad() (:889); not computing them is the same result without D's weight-gradient pass.
         set_requires_grad(Disc, False)
+        try:
+            total_gen_loss, total_hist_loss, pl_len = self._g_phase(
+                alpha, apply_path_penalty, gs, early, g_forward, aug, total_gen_loss, total_hist_loss)
+        finally:
+            set_requires_grad(Disc, True)
+        GAN._reduce_g()
+        GAN.G_opt.step()
+
+        return torch.stack([total_disc_loss, total_gen_loss, total_hist_loss, gp_val.reshape(()),
+                            q_val.reshape(()), pl_len if pl_len is not None else zero()]).double()
+
+    def _g_phase(self, alpha, apply_path_penalty, gs, early, g_forward, aug, total_gen_loss, total_hist_loss):
+        """Generator phase of the step (reference :934-989); D's parameters are frozen by the caller."""
+        GAN, dev, Disc, acc = self.GAN, self.device, self.GAN.D, self.gradient_accumulate_every
+        pl_len = None
         d_updated = False
         for i in range(acc):
             if early is not None:
@@ -612,14 +685,9 @@ class Trainer():
                         gen_loss = gen_loss + pl_loss
             gen_loss = gen_loss / acc
             gen_loss.backward()
-            total_gen_loss += loss.detach() / acc
-            total_hist_loss += histogram_loss.detach() / acc
-        set_requires_grad(Disc, True)
-        GAN._reduce_g()
-        GAN.G_opt.step()
-
-        return torch.stack([total_disc_loss, total_gen_loss, total_hist_loss, gp_val.reshape(()),
-                            q_val.reshape(()), pl_len if pl_len is not None else zero()]).double()
+            total_gen_loss = total_gen_loss + loss.detach() / acc
+            total_hist_loss = total_hist_loss + histogram_loss.detach() / acc
+        return total_gen_loss, total_hist_loss, pl_len
 
     def train(self, alpha=2):
         assert self.loader is not None, ('You must first initialize the data source with '
@@ -627,6 +695,8 @@ class Trainer():
         torch.autograd.set_detect_anomaly(False)
         if self.GAN is None:
             self.init_GAN()
+        if self._nan_checkpoint is not None:       # a NaN surfaced while a statistic was read between two train() calls
+            self._raise_nan(self._nan_checkpoint)
         GAN = self.GAN
         GAN.train()
         _freeze_gc_once(self)
@@ -634,57 +704,111 @@ class Trainer():
         apply_gradient_penalty = self.steps % 4 == 0
         apply_path_penalty = self.steps % 32 == 0
         graphed = self._graph_eligible(apply_gradient_penalty, apply_path_penalty)
-        if graphed:
-            stats = self._graphed_step(alpha, apply_gradient_penalty)
-        else:
-            stats = self._device_step(alpha, apply_gradient_penalty, apply_path_penalty, None)
+        try:
+            if graphed:
+                stats = self._graphed_step(alpha, apply_gradient_penalty)
+            else:
+                stats = self._device_step(alpha, apply_gradient_penalty, apply_path_penalty, None)
+        except NanException:
+            raise
+        except Exception:
+            if self.GAN is not None:
+                self._reset_after_failed_step()
+            raise
 
-        # ---- one read-back for everything the host needs (reference: >= 7 syncs)
-        # host time spent enqueueing this step (everything before the one blocking read-back); graphed: the replay call
+        # host time spent enqueueing this step (everything before the read-back); graphed: the replay call
         self.host_enqueue_ms = (perf_counter() - t_host0) * 1e3
         self.last_step_graphed = bool(graphed) and self.graph_mode != '2' and not getattr(self, '_graph_failed', False)
         self._t_host0 = t_host0
+
+        # ---- ONE read-back for everything the host needs (reference: >= 7 `.item()` syncs), deferred by one step: the
+        # packed statistics go to pinned host memory asynchronously; what the host waits for below is the PREVIOUS
+        # step's copy, which completes while this step's launches are already queued -- the queue never drains at a step
+        # boundary (profiles/r02_step_timeline.txt: 0.69 + 0.47 ms idle per boundary with the blocking read-back).
         if ddp.is_dist():
             nan_flag = torch.isnan(stats[:4]).any().double().reshape(1)
             packed = torch.cat([stats, nan_flag])
             torch.distributed.all_reduce(packed[:6], op=torch.distributed.ReduceOp.SUM)
             torch.distributed.all_reduce(packed[6:], op=torch.distributed.ReduceOp.MAX)
             packed[:6] /= ddp.world_size()
-            host = packed.cpu().numpy()
-            has_nan = host[6] > 0 or np.isnan(host[:2]).any() or np.isnan(host[3])
         else:
-            host = stats.cpu().numpy()
-            has_nan = bool(np.isnan(host[:2]).any() or np.isnan(host[3]))     # incl. the gradient penalty (reference's raise_if_nan on disc_loss)
+            packed = torch.cat([stats, torch.zeros(1, dtype=stats.dtype, device=stats.device)])
+        host = self._host_buffer()
+        host.copy_(packed, non_blocking=True)
+        ev = torch.cuda.Event(enable_timing=self.keep_step_events)
+        ev.record()
+        checkpoint_num = floor(self.steps / self.save_every)
+        self._pending.append((ev, host, dict(step=self.steps, gp=apply_gradient_penalty, pl=apply_path_penalty,
+                                             checkpoint=checkpoint_num)))
+        if self.keep_step_events:
+            self.step_events.append((self.steps, ev))
+        will_save = self.run_save and self.steps % self.save_every == 0
+        will_eval = self.run_evaluate and (self.steps % 1000 == 0 or (self.steps % 100 == 0 and self.steps < 2500))
+        # save / evaluate look at this step's result (the reference checks for NaN before it saves, :1002-1014)
+        self._drain(1 if (self.lazy_stats and not will_save and not will_eval) else 0, in_train=True)
         if self.graph_mode == 'auto' and getattr(self, '_graph_auto', None) is None and self.steps >= 2 \
                 and not (apply_gradient_penalty or apply_path_penalty):
             # eager plain step: share of its wall time (up to the read-back's return) the host spent enqueueing
             self.__dict__.setdefault('_host_ratio', []).append(self.host_enqueue_ms / max((perf_counter() - t_host0) * 1e3, 1e-3))
-        self.d_loss, self.g_loss, self.h_loss = float(host[0]), float(host[1]), float(host[2])
-        if apply_gradient_penalty:
-            self.last_gp_loss = float(host[3])
-        self.q_loss = float(host[4])
+            if len(self._host_ratio) == 2 and self.is_main and os.environ.get('HG_VERBOSE'):
+                print(f'train step: HG_GRAPH=auto host-enqueue share {self._host_ratio} (graph above {GRAPH_AUTO_RATIO})')
 
-        # moving averages (reference :991-1000)
-        if apply_path_penalty and not np.isnan(host[5]):
-            self.pl_mean = self.pl_length_ma.update_average(self.pl_mean, float(host[5]))
+        # moving averages (reference :996-1000)
         if self.steps % 10 == 0 and self.steps > 20000:
             GAN.EMA()
         if self.steps <= 25000 and self.steps % 1000 == 2:
             GAN.reset_parameter_averaging()
 
-        # save from NaN errors (reference :1002-1010); the flag is all-reduced so every rank raises
-        checkpoint_num = floor(self.steps / self.save_every)
-        if has_nan:
-            print(f'NaN detected for generator or discriminator. Loading from checkpoint #{checkpoint_num}')
-            self.load(checkpoint_num)
-            raise NanException
-
-        if self.run_save and self.steps % self.save_every == 0:
+        if will_save:
             self.save(checkpoint_num)
-        if self.run_evaluate and (self.steps % 1000 == 0 or (self.steps % 100 == 0 and self.steps < 2500)):
+        if will_eval:
             self.evaluate(floor(self.steps / 1000))
         self.steps += 1
         self.av = None
+
+    # ---- deferred statistics -----------------------------------------------------------------
+    def _host_buffer(self):
+        """Pinned host staging for one step's packed statistics (two rotate: one in flight, one being read)."""
+        ring = self.__dict__.setdefault('_host_ring', [])
+        for buf in ring:
+            if not any(buf is h for _, h, _ in self._pending):
+                return buf
+        buf = torch.empty(7, dtype=torch.float64).pin_memory()
+        ring.append(buf)
+        return buf
+
+    def _drain(self, keep, in_train):
+        """Consume the statistics of all pending steps but the newest `keep`: losses, the path-length moving average
+        (reference :991-994) and the NaN check (:1002-1010).  in_train=False (a statistic read between two train()
+        calls): a NaN is remembered and raised by the next train() call, inside the caller's retry loop."""
+        while len(self._pending) > keep:
+            ev, host_t, meta = self._pending.pop(0)
+            ev.synchronize()
+            host = host_t.numpy().copy()
+            # generator loss incl. the histogram term and the gradient penalty, as the reference's checks on gen_loss /
+            # disc_loss (:978, :925); under data parallelism the flag is the all-reduced one so every rank raises
+            has_nan = bool(host[6] > 0 or np.isnan(host[:4]).any())
+            d = self.__dict__
+            d['_stat_d_loss'], d['_stat_g_loss'], d['_stat_h_loss'] = float(host[0]), float(host[1]), float(host[2])
+            if meta['gp']:
+                d['_stat_last_gp_loss'] = float(host[3])
+            d['_stat_q_loss'] = float(host[4])
+            if meta['pl'] and not np.isnan(host[5]):
+                d['_stat_pl_mean'] = self.pl_length_ma.update_average(d.get('_stat_pl_mean', 0), float(host[5]))
+            if has_nan:
+                self._pending.clear()
+                if in_train:
+                    self._raise_nan(meta['checkpoint'])
+                self._nan_checkpoint = meta['checkpoint']
+                return
+
+    def _raise_nan(self, checkpoint_num):
+        # save from NaN errors (reference :1002-1010)
+        self._nan_checkpoint = None
+        self._pending.clear()
+        print(f'NaN detected for generator or discriminator. Loading from checkpoint #{checkpoint_num}')
+        self.load(checkpoint_num)
+        raise NanException
 
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -705,7 +829,10 @@ class Trainer():
             else:
                 n = self.rng.image_noise(num_rows ** 2, image_size)
             if load_latent_file is not None:
-                latents = np.load(load_latent_file)
+                # [(latent (n, 512), layers)] as saved below: an object array (the reference's plain np.save / np.load of
+                # this list, :1046, :1060, only round-trips on NumPy versions that still built ragged object arrays)
+                latents = [(torch.as_tensor(np.asarray(z, dtype=np.float32)).to(self.device), int(layers))
+                           for z, layers in np.load(load_latent_file, allow_pickle=True)]
             else:
                 latents = self.rng.noise_list(num_rows ** 2, num_layers - 2, latent_dim)
         generated_images = self.generate_truncated(self.GAN.SE, self.GAN.HE, self.GAN.GE, hist_batch, latents, n,
@@ -717,7 +844,10 @@ class Trainer():
         if save_noise_latent:
             Path(f'temp/{self.name}').mkdir(parents=True, exist_ok=True)
             np.save(f'temp/{self.name}/{str(num)}-noise.npy', n.clone().cpu().numpy())
-            np.save(f'temp/{self.name}/{str(num)}-latents.npy', latents)
+            arr = np.empty((len(latents), 2), dtype=object)
+            for i, (z, layers) in enumerate(latents):
+                arr[i, 0], arr[i, 1] = z.detach().cpu().numpy(), int(layers)
+            np.save(f'temp/{self.name}/{str(num)}-latents.npy', arr, allow_pickle=True)
         return generated_images
 
     @torch.no_grad()

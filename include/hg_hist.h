@@ -44,6 +44,11 @@ extern "C" {
 #define HG_RESIZE_SAMPLING 2  /* x.index_select(2,row_idx).index_select(3,col_idx)        */
 
 typedef struct hg_hist_params {
+  /* sizeof(hg_hist_params) as the CALLER compiled it (ABI guard, since version 102): every entry point returns
+   * HG_EINVAL when it differs from the library's, so a caller built against an older header -- or one that did not
+   * zero the struct and fill this in -- is rejected instead of having trailing fields (proj_cache: a pointer the
+   * forward WRITES through) read as garbage. */
+  uint32_t struct_size;
   /* input image batch x: (B, C>=3, H, W), element strides (any layout) */
   int32_t B, C, H, W;
   int64_t stride_b, stride_c, stride_h, stride_w;
@@ -84,6 +89,11 @@ const char *hg_error_string(int code);
  * [0] = max relative error where |ln x| >= 1e-3, [1] = max absolute error elsewhere.  The classification's margins
  * assume [0] <= 3e-7 and [1] <= 3e-7 (hg_hist.hip: kFastLogRel, kFastAbs carry the roundings on top). */
 int hg_selftest_fastlog(float *out2, void *stream);
+
+/* 1 when a forward / backward pair with these params uses `proj_cache` (the dense MFMA kernels), 0 when it would be
+ * ignored (thresholding, the truncated-RBF scatter / gather pair): lets the caller skip the 32 B / pixel allocation.
+ * Negative HG_E* on bad params. */
+int hg_rgbuv_hist_uses_proj_cache(const hg_hist_params *p);
 
 /* Bytes of scratch each call needs for these params (both may be queried at once). */
 int hg_rgbuv_hist_workspace_bytes(const hg_hist_params *p, size_t *fwd_bytes, size_t *bwd_bytes);

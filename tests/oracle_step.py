@@ -1,0 +1,127 @@
+"""Test helper (NOT a test module): one HistoGAN optimisation step evaluated with oracle/ -- the functional
+restatement of the reference's networks, histogram block, Hellinger loss and DiffGrad -- in any dtype on any device.
+
+Follows the reference step line by line (histoGAN/histoGAN.py:853-1020): D phase (generator under no_grad, hinge
+loss, gradient penalty on gradient-penalty steps), DiffGrad on D, G phase against the UPDATED discriminator
+(adversarial + alpha * Hellinger on relu(G(z)), image-space path-length term on path-length steps), DiffGrad on
+G / S / H.  dtype float64 gives the "truth" the 2x criterion of SURVEY.md section 8c measures distances to; float32
+on the GPU is the reference's own numerics on this machine (aten / MIOpen / rocBLAS).
+"""
+import torch
+import torch.nn.functional as F
+
+
+class ReplayRng:
+    """Feeds Trainer.train the tensors the oracle step uses (same draw order as the reference, :166-189)."""
+
+    mode = 'replay'
+
+    def __init__(self, device, B, L, LAT, S, seed, tt=1, dtype=torch.float32):
+        g = torch.Generator().manual_seed(seed)
+        self.dev, self.dtype = device, dtype
+        self.z = [torch.randn(B, LAT, generator=g) for _ in range(4)]
+        self.img_noise = [torch.rand(B, S, S, 1, generator=g) for _ in range(2)]
+        self.pl = torch.randn(B, L - 2, LAT, generator=g)
+        self.zi = self.ni = 0
+        self.tt = tt
+
+    def _t(self, x):
+        return x.to(self.dev).to(self.dtype)
+
+    def noise(self, n, d):
+        z = self.z[self.zi]; self.zi += 1
+        return self._t(z)
+
+    def noise_list(self, n, layers, d):
+        return [(self.noise(n, d), layers)]
+
+    def mixed_list(self, n, layers, d):
+        return self.noise_list(n, self.tt, d) + self.noise_list(n, layers - self.tt, d)
+
+    def image_noise(self, n, s):
+        x = self.img_noise[self.ni]; self.ni += 1
+        return self._t(x)
+
+    def randn_like(self, t):
+        return self._t(self.pl)
+
+
+def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hist_kw=None, optimizer=True):
+    """sd0: GAN.state_dict() before the step (any device / dtype; moved to rng's).  batches: [D-phase batch, G-phase
+    batch] of {'images', 'histograms'}.  gp / pl: gradient-penalty / path-length step.  Returns a dict with the loss
+    values, the gradients {('D', name): g, ('G', name): g, ...} and (optimizer=True) the updated parameters."""
+    from oracle import histogan_nets as N
+    from oracle import rgbuv_hist as OH
+    dev, dt = rng.dev, rng.dtype
+    hist_kw = dict(hist_kw or {})
+    cvt = lambda t: t.detach().to(dev).to(dt)
+    sub = lambda p: {k[len(p) + 1:]: cvt(v).clone().requires_grad_(True) for k, v in sd0.items()
+                     if k.startswith(p + '.') and v.dtype.is_floating_point}
+    sG, sD, sS, sH = sub('G'), sub('D'), sub('S'), sub('H')
+    nblk = L + 1
+    B = batches[0]['images'].shape[0]
+    LAT = sG['blocks.0.to_style1.weight'].shape[1]
+    S_ = batches[0]['images'].shape[-1]
+
+    def w_hw(style, hist):
+        w = [(N.vectorizer(sS, z, 'net'), n) for z, n in style]
+        hw = N.vectorizer(sH, hist, 'fcs')[:, None, :]
+        return N.styles_def_to_tensor(w), torch.cat((hw, hw), 1)
+
+    def diffgrad(params, grads):
+        for k, gr in zip(params, grads):
+            st = dict(step=0, exp_avg=torch.zeros_like(gr), exp_avg_sq=torch.zeros_like(gr),
+                      previous_grad=torch.zeros_like(gr))
+            with torch.no_grad():
+                N.diffgrad_step(params[k], gr, st, lr=lr, betas=(0.5, 0.9))
+
+    out = {}
+    # ---- D phase (:889-932)
+    style = rng.mixed_list(B, L - 2, LAT); noise = rng.image_noise(B, S_)
+    img = cvt(batches[0]['images']).clone().requires_grad_(True)
+    with torch.no_grad():
+        w, hw = w_hw(style, cvt(batches[0]['histograms']))
+        fake = N.generator(sG, w, hw, noise, L)
+    fake_out = N.discriminator(sD, fake, nblk)
+    real_out = N.discriminator(sD, img, nblk)
+    div = (F.relu(1 + real_out) + F.relu(1 - fake_out)).mean()
+    d_loss = div
+    if gp:
+        gpv = N.gradient_penalty(img, real_out)
+        d_loss = d_loss + gpv
+        out['gp'] = float(gpv)
+    dk = list(sD.keys())
+    dgr = torch.autograd.grad(d_loss, [sD[k] for k in dk])
+    out['d_loss'] = float(div)
+    grads = {('D', k): g.detach() for k, g in zip(dk, dgr)}
+    if optimizer:
+        diffgrad({k: sD[k] for k in dk}, dgr)
+    del fake_out, real_out, div, d_loss, dgr
+    # ---- G phase (:934-989), against the UPDATED discriminator
+    style = rng.mixed_list(B, L - 2, LAT); noise = rng.image_noise(B, S_)
+    tgt = cvt(batches[1]['histograms'])
+    w, hw = w_hw(style, tgt)
+    gen_img = N.generator(sG, w, hw, noise, L)
+    fo = N.discriminator(sD, gen_img, nblk)
+    gh = OH.rgbuv_hist(F.relu(gen_img), h=HB, truth=dt == torch.float64, **hist_kw)
+    h_loss = OH.hellinger_loss(tgt, gh.to(dt), alpha)
+    g_loss = fo.mean() + h_loss
+    if pl:
+        std = 0.1 / (w.std(dim=0, keepdim=True) + 1e-8)
+        w2 = w + rng.randn_like(w) / (std + 1e-8)
+        pll = ((N.generator(sG, w2, hw, noise, L) - gen_img) ** 2).mean(dim=(1, 2, 3))
+        out['pl'] = float(pll.mean())
+        g_loss = g_loss + ((pll - pl_mean) ** 2).mean()
+    groups = [('G', sG), ('S', sS), ('H', sH)]
+    keys = [(p, k) for p, s in groups for k in s]
+    ggr = torch.autograd.grad(g_loss, [dict(groups)[p][k] for p, k in keys])
+    out['g_loss'], out['h_loss'] = float(fo.mean()), float(h_loss)
+    out['gen_img'] = gen_img.detach()
+    grads.update({pk: g.detach() for pk, g in zip(keys, ggr)})
+    if optimizer:
+        for p, s in groups:
+            ks = [k for pp, k in keys if pp == p]
+            diffgrad({k: s[k] for k in ks}, [grads[(p, k)] for k in ks])
+    out['grads'] = grads
+    out['params'] = {(p, k): v.detach() for p, s in [('D', sD)] + groups for k, v in s.items()}
+    return out

@@ -1,0 +1,47 @@
+"""bench.py end to end on the GPU box, including the data-parallel path on RCCL at world size 1 (the
+driver's 8-GPU run must not be the first time `init_process_group('nccl', device_id=...)`, the AVG gradient all-reduce,
+the statistics all-reduces and the global-batch Hellinger term execute on RCCL)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _bench(extra_env, *args):
+    env = dict(os.environ, **extra_env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    return json.loads(line)
+
+
+def test_bench_train_on_rccl_world1(gpu_device):
+    env = dict(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               HG_DIST_BACKEND='nccl', HG_DIST_FORCE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = _bench(env, '--gpus', '1', '--steps', '5', '--warmup', '1', '--batch', '4', '--no-roofline')
+    assert out['ddp']['backend'] == 'nccl' and out['ddp']['grad_allreduce_op'].startswith('AVG')
+    assert out['ddp']['ranks'][0]['world_size'] == 1 and out['ddp']['ranks'][0]['device'] == 'cuda:0'
+    assert set(out['ddp']['allreduce']) == {'D', 'G+S+H'} and out['value'] > 0
+
+
+def test_bench_hist_line_has_the_contract_fields(gpu_device):
+    out = _bench({}, '--workload', 'hist', '--steps', '5', '--warmup', '2', '--cpu-images', '1', '--cpu-reps', '1')
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in out, k
+    assert out['roofline']['bound'] == 'mfma' and 0 < out['roofline']['frac'] < 1
+    assert out['cpu_baseline']['kind'] == 'port' and out['cpu_baseline']['cpu']
+    assert out['roofline']['thresholding']['bound'] == 'hbm'

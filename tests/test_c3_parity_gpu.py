@@ -1,0 +1,276 @@
+"""Parity AT THE BENCH CONFIGURATION (BASELINE.json configs[2]: 256^2, network_capacity 16, h = 64) -- VERDICT r2 item 1.
+
+(a) every distinct convolution launch of the C3 train step -- (batch, K, N, map, kernel, stride) x {output, data
+    gradient, weight gradient}, batch 32 and the [fake; real] batch 64 -- against torch's fp64 convolution;
+(b) Generator(256, 512, 16) / Discriminator(256, 16) forward, backward and gradient penalty at B = 2 against
+    oracle/histogan_nets.py evaluated in fp64 on the GPU (weights from a seed);
+(c) one plain and one gradient-penalty Trainer.train() step at 256^2 / capacity 16 / B = 2 against the oracle step;
+(d) generator-side gradients judged by SURVEY 8(c)'s criterion: our distance to the fp64 evaluation within 2x the
+    distance of the reference's own fp32 numerics (the oracle in fp32 on aten / MIOpen / rocBLAS) to it.
+
+Reference: histoGAN/histoGAN.py:404-440 (Conv2DMod), 529-631 (Generator, Discriminator), 156-163 (gradient_penalty),
+853-1020 (Trainer.train).  Measured distances are written to gpurun_out/c3_parity.json (copied to profiles/)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT, relmax
+from oracle_step import ReplayRng, oracle_train_step
+
+pytestmark = pytest.mark.gpu
+
+S_, CAP, HB, LAT = 256, 16, 64, 512
+_REPORT = {}
+
+
+def _record(key, val):
+    _REPORT[key] = val
+    try:
+        d = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'c3_parity.json'), 'w') as f:
+            json.dump(_REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _rms(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+# ---- (a) every convolution launch of the C3 step ------------------------------------------------------------------
+def c3_conv_plan(B=32):
+    """(tag, batch, K, N, S, k, stride, passes) of one C3 train step: the generator's modulated convolutions at batch B
+    (reference filter arithmetic :541-543) and the discriminator's at 2B ([fake; real], D phase) and B (G phase,
+    gradient penalty) (:582-585)."""
+    plan = []
+    gf = [4 * CAP] + [CAP * 2 ** (i + 1) for i in range(7)][::-1]            # 64, 2048, 1024, ..., 32
+    for i in range(7):
+        ci, co, S = gf[i], gf[i + 1], 4 * 2 ** i
+        plan.append((f'G{i}.conv1', B, ci, co, S, 3, 1, 'fdw' if i else 'fw'))
+        plan.append((f'G{i}.conv2', B, co, co, S, 3, 1, 'fdw'))
+        plan.append((f'G{i}.rgb', B, co, 3, S, 1, 1, 'fdw'))
+    df = [3] + [CAP * 2 ** i for i in range(8)]                               # 3, 16, ..., 2048
+    for i in range(8):
+        ci, co, S = df[i], df[i + 1], 256 // 2 ** i
+        for b in (2 * B, B):
+            plan.append((f'D{i}.res', b, ci, co, S, 1, 1, 'fdw'))
+            plan.append((f'D{i}.c1', b, ci, co, S, 3, 1, 'fdw'))
+            plan.append((f'D{i}.c2', b, co, co, S, 3, 1, 'fdw'))
+            if i < 7:
+                plan.append((f'D{i}.down', b, co, co, S, 3, 2, 'fdw'))
+    seen, out = set(), []
+    for p in plan:
+        if p[1:] not in seen:
+            seen.add(p[1:])
+            out.append(p)
+    return out
+
+
+@pytest.mark.parametrize('tag,B,K,N,S,k,stride,passes', c3_conv_plan(), ids=lambda v: str(v))
+def test_c3_conv_launch_matches_fp64(tag, B, K, N, S, k, stride, passes, gpu_device):
+    """Output / data gradient / weight gradient (+ bias gradient) of the launch through the autograd Functions (C ABI
+    hg_conv2d_fwd / _dgrad / _wgrad) vs F.conv2d in fp64 on the same device.  Accumulation depth up to 9 x 2048 (output)
+    and 64 x 256^2 pixels (weight gradient): bars 5e-6 / 5e-6 / 1e-5 max-norm relative -- half of / a tenth of the
+    1e-5 / 1e-4 parity bars."""
+    from histogan_amd.conv import conv2d
+    g = torch.Generator(device='cpu').manual_seed(B * 7 + K * 13 + N * 3 + S + k + stride)
+    dev = gpu_device
+    x = torch.randn(B, K, S, S, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(N, K, k, k, generator=g) / (K * k * k) ** 0.5).to(dev).requires_grad_(True)
+    b = torch.randn(N, generator=g).to(dev).requires_grad_(True)
+    out = conv2d(x, w, b, stride)
+    So = (S - 1) // stride + 1
+    go = torch.randn(B, N, So, So, generator=g).to(dev)
+    gx, gw, gb = torch.autograd.grad(out, (x, w, b), go)
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    ref = F.conv2d(xd, wd, bd, stride=stride, padding=k // 2)
+    rx, rw, rb = torch.autograd.grad(ref, (xd, wd, bd), go.double())
+    e = dict(out=_rel(out.detach(), ref.detach()), gx=_rel(gx, rx), gw=_rel(gw, rw), gb=_rel(gb, rb))
+    _record(f'conv/{tag}/B{B}', e)
+    assert out.shape == ref.shape
+    assert e['out'] <= 5e-6 and e['gx'] <= 5e-6 and e['gw'] <= 1e-5 and e['gb'] <= 1e-5, e
+
+
+# ---- (b) networks at 256^2 / capacity 16 ---------------------------------------------------------------------------
+def _sd(module, dev, dt):
+    return {k: v.detach().to(dev).to(dt).clone().requires_grad_(True) for k, v in module.state_dict().items()}
+
+
+def test_c3_generator_matches_fp64_oracle(gpu_device):
+    """Generator(256, 512, 16): rgb and the gradients of every parameter / styles / hists against the oracle in fp64
+    (reference :529-568); bars 1e-5 (output) / 1e-4 (gradients), and within 2x of the fp32 oracle's own distance."""
+    from histoGAN import Generator
+    from oracle import histogan_nets as N
+    torch.manual_seed(21)
+    dev, B = gpu_device, 2
+    G = Generator(S_, LAT, network_capacity=CAP).to(dev)
+    with torch.no_grad():
+        for blk in G.blocks:        # the reference zero-initialises the noise layers (:692-696): exercise them
+            blk.to_noise1.weight.normal_(std=0.3); blk.to_noise2.weight.normal_(std=0.3)
+            blk.to_noise1.bias.normal_(std=0.1); blk.to_noise2.bias.normal_(std=0.1)
+    L = G.num_layers
+    styles = torch.randn(B, L - 2, LAT, device=dev, requires_grad=True)
+    hists = torch.randn(B, 2, LAT, device=dev, requires_grad=True)
+    noise = torch.rand(B, S_, S_, 1, device=dev)
+    go = torch.randn(B, 3, S_, S_, device=dev)
+    names = [n for n, _ in G.named_parameters()]
+    params = dict(G.named_parameters())
+    rgb = G(styles, hists, noise)
+    grads = torch.autograd.grad(rgb, [styles, hists] + [params[n] for n in names], go)
+
+    def oracle(dt):
+        sd = _sd(G, dev, dt)
+        st, hi = styles.detach().to(dt).requires_grad_(True), hists.detach().to(dt).requires_grad_(True)
+        o = N.generator(sd, st, hi, noise.to(dt), L)
+        gr = torch.autograd.grad(o, [st, hi] + [sd[n] for n in names], go.to(dt))
+        return o.detach(), gr
+
+    t_rgb, t_gr = oracle(torch.float64)
+    r_rgb, r_gr = oracle(torch.float32)
+    e_out = _rel(rgb.detach(), t_rgb)
+    worst = max(((_rel(a, t), n) for a, t, n in zip(grads, t_gr, ['styles', 'hists'] + names)))
+    ours_rms = max(_rms(a, t) for a, t in zip(grads, t_gr))
+    ref_rms = max(_rms(a, t) for a, t in zip(r_gr, t_gr))
+    _record('generator', dict(out_ours=e_out, out_ref32=_rel(r_rgb, t_rgb), grad_worst=worst[0], grad_worst_name=worst[1],
+                              grad_worst_ref32=max(_rel(a, t) for a, t in zip(r_gr, t_gr)), grad_rms_ours=ours_rms,
+                              grad_rms_ref32=ref_rms))
+    assert e_out <= 1e-5
+    assert worst[0] <= 1e-4, worst
+    assert ours_rms <= 2 * ref_rms + 1e-7
+
+
+def test_c3_discriminator_and_gradient_penalty_match_fp64_oracle(gpu_device):
+    """Discriminator(256, 16): logits, gradient penalty (double backward through every layer, 2048 channels on 2x2 maps
+    included) and the parameter gradients of hinge + penalty vs the oracle in fp64 (reference :573-631, 156-163)."""
+    from histoGAN import Discriminator
+    from histoGAN.histoGAN import gradient_penalty
+    from oracle import histogan_nets as N
+    torch.manual_seed(22)
+    dev, B = gpu_device, 2
+    D = Discriminator(S_, network_capacity=CAP).to(dev)
+    img = torch.rand(B, 3, S_, S_, device=dev)
+    x = img.clone().requires_grad_(True)
+    logits, _ = D(x)
+    gp = gradient_penalty(x, logits)
+    loss = torch.relu(1 + logits).mean() + gp
+    names = [n for n, _ in D.named_parameters()]
+    params = dict(D.named_parameters())
+    grads = torch.autograd.grad(loss, [params[n] for n in names])
+
+    def oracle(dt):
+        sd = _sd(D, dev, dt)
+        xc = img.to(dt).clone().requires_grad_(True)
+        lo = N.discriminator(sd, xc, len(D.blocks))
+        gpo = N.gradient_penalty(xc, lo)
+        gr = torch.autograd.grad(torch.relu(1 + lo).mean() + gpo, [sd[n] for n in names])
+        return lo.detach(), float(gpo), gr
+
+    t_lo, t_gp, t_gr = oracle(torch.float64)
+    r_lo, r_gp, r_gr = oracle(torch.float32)
+    worst = max(((_rel(a, t), n) for a, t, n in zip(grads, t_gr, names)))
+    ours_rms = max(_rms(a, t) for a, t in zip(grads, t_gr))
+    ref_rms = max(_rms(a, t) for a, t in zip(r_gr, t_gr))
+    _record('discriminator', dict(logits_ours=_rel(logits.detach(), t_lo), logits_ref32=_rel(r_lo, t_lo),
+                                  gp_ours=abs(float(gp) - t_gp) / max(1.0, abs(t_gp)), gp_ref32=abs(r_gp - t_gp) / max(1.0, abs(t_gp)),
+                                  gp_value=t_gp, grad_worst=worst[0], grad_worst_name=worst[1],
+                                  grad_worst_ref32=max(_rel(a, t) for a, t in zip(r_gr, t_gr)),
+                                  grad_rms_ours=ours_rms, grad_rms_ref32=ref_rms))
+    assert _rel(logits.detach(), t_lo) <= 1e-5
+    assert abs(float(gp) - t_gp) <= 1e-4 * max(1.0, abs(t_gp))
+    assert worst[0] <= 1e-4, worst
+    assert ours_rms <= 2 * ref_rms + 1e-7
+
+
+# ---- (c) + (d) one train step at 256^2 / capacity 16 -----------------------------------------------------------------
+@pytest.mark.parametrize('step_no', [1, 4, 0], ids=['plain', 'gradient-penalty', 'gp+path-length'])
+def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
+    """Trainer.train() at 256^2, capacity 16, h = 64, trainer-default histogram (256 -> 150 bilinear), B = 2: a plain
+    step (one [fake; real] discriminator pass), a gradient-penalty step and step 0 (penalty + path-length term), against the oracle step in fp64 (truth) and
+    in fp32 (the reference's numerics on this GPU).  Losses 1e-4; discriminator gradients 1e-4; generator-side gradients:
+    distance to truth within 2x the fp32 reference's (they pass relu / clamp edges of the histogram, whose per-pixel
+    gradient ~ 1 / (x + 1e-6) amplifies fp32 rounding of the generator for BOTH evaluations alike)."""
+    from histoGAN import Trainer
+    from oracle import rgbuv_hist as OH
+    torch.manual_seed(31)
+    dev, B, ALPHA, LR = gpu_device, 2, 2.0, 2e-4
+    tr = Trainer('c3', tmp_path / 'r', tmp_path / 'm', S_, CAP, batch_size=B, lr=LR, hist_bin=HB, hist_insz=150,
+                 hist_resizing='interpolation', mixed_prob=1.1)
+    tr.graph_mode = '0'
+    tr.run_evaluate = tr.run_save = False
+    tr.init_GAN()
+    GAN = tr.GAN
+    with torch.no_grad():
+        for blk in GAN.G.blocks:
+            blk.to_noise1.weight.normal_(std=0.3); blk.to_noise2.weight.normal_(std=0.3)
+    L = GAN.G.num_layers
+    sd0 = {k: v.detach().clone() for k, v in GAN.state_dict().items()}
+    gen = torch.Generator().manual_seed(6)
+    batches = []
+    for _ in range(2):
+        img = torch.rand(B, 3, S_, S_, generator=gen)
+        hist = OH.rgbuv_hist(torch.rand(B, 3, S_, S_, generator=gen), h=HB)
+        batches.append({'images': img.to(dev), 'histograms': hist.to(dev)})
+    tr.loader = iter(batches)
+    tr.rng = ReplayRng(dev, B, L, LAT, S_, 78, tt=2)
+    tr.steps = step_no
+    tr.train(alpha=ALPHA)
+    new = {k: v.detach() for k, v in GAN.state_dict().items()}
+    gp, pl = step_no % 4 == 0, step_no % 32 == 0
+
+    truth = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, 78, tt=2, dtype=torch.float64), L, HB, ALPHA,
+                              LR, gp, pl)
+    ref32 = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, 78, tt=2), L, HB, ALPHA, LR, gp, pl)
+    rec = dict(d_loss=abs(tr.d_loss - truth['d_loss']), g_loss=abs(tr.g_loss - truth['g_loss']),
+               h_loss=abs(tr.h_loss - truth['h_loss']))
+    assert rec['d_loss'] <= 1e-4 and rec['g_loss'] <= 1e-4 and rec['h_loss'] <= 1e-4, rec
+    if gp:
+        rec['gp'] = abs(tr.last_gp_loss - truth['gp']) / max(1.0, abs(truth['gp']))
+        assert rec['gp'] <= 1e-4, rec
+
+    # discriminator gradients of the D phase (still in its flat gradient buffer; the G phase does not touch them)
+    worst_d, off = (0.0, None), 0
+    for prm in GAN._flat_d.params:
+        n = prm.numel()
+        name = next(k for k, v in GAN.D.named_parameters() if v is prm)
+        worst_d = max(worst_d, (_rel(GAN._flat_d.grad[off:off + n].view(prm.shape), truth['grads'][('D', name)]), name))
+        off += n
+    rec['d_grad_worst_ours'], rec['d_grad_worst_name'] = worst_d
+    rec['d_grad_worst_ref32'] = max(_rel(ref32['grads'][pk], t) for pk, t in truth['grads'].items() if pk[0] == 'D')
+    assert worst_d[0] <= 1e-4, worst_d
+
+    # generator-side gradients are still in the flat buffer (zeroed at the start of the next step)
+    ours_g, ref_g, worst_g = [], [], (0.0, None)
+    for (p, k), t in truth['grads'].items():
+        if p == 'D':
+            continue
+        mine = dict(getattr(GAN, p).named_parameters())[k].grad.detach()
+        ours_g.append((mine.double() - t).flatten()); ref_g.append((ref32['grads'][(p, k)].double() - t).flatten())
+        worst_g = max(worst_g, (_rel(mine, t), f'{p}.{k}'))
+    tn = torch.cat([t.flatten() for (p, k), t in truth['grads'].items() if p != 'D']).norm()
+    rec['g_grad_rms_ours'] = float(torch.cat(ours_g).norm() / tn)
+    rec['g_grad_rms_ref32'] = float(torch.cat(ref_g).norm() / tn)
+    rec['g_grad_worst_ours'], rec['g_grad_worst_name'] = worst_g
+    rec['g_grad_worst_ref32'] = max(_rel(ref32['grads'][pk], t) for pk, t in truth['grads'].items() if pk[0] != 'D')
+    _record(f'train_step/{"gp+pl" if pl else "gp" if gp else "plain"}', rec)
+    assert rec['g_grad_rms_ours'] <= 2 * rec['g_grad_rms_ref32'] + 1e-7, rec
+    assert rec['g_grad_worst_ours'] <= max(1e-4, 2 * rec['g_grad_worst_ref32']), rec
+
+    # parameters after the step.  The first DiffGrad step is ~ lr * sigmoid(|g|) * g / (|g| + 3e-8): compare the deltas
+    # where the gradient is not rounding noise (elsewhere the sign itself is ill-conditioned)
+    for (p, k), t in truth['params'].items():
+        gr = truth['grads'][(p, k)]
+        mask = gr.abs() > 5e-2 * gr.abs().max()
+        dn = (new[f'{p}.{k}'].double() - sd0[f'{p}.{k}'].double())
+        do = (t - sd0[f'{p}.{k}'].double())
+        assert float((dn - do).abs()[mask].max()) <= 0.02 * LR, (p, k)

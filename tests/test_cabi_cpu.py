@@ -43,6 +43,7 @@ def test_version_and_error_strings(L):
 
 def _params(L, **kw):
     p = L.HgHistParams()
+    p.struct_size = ctypes.sizeof(L.HgHistParams)
     p.B, p.C, p.H, p.W = 2, 3, 16, 16
     p.stride_b, p.stride_c, p.stride_h, p.stride_w = 3 * 256, 256, 16, 1
     p.Hs, p.Ws, p.resize_mode = 16, 16, 0
@@ -61,6 +62,28 @@ def test_workspace_query_and_validation(L):
     codes = [L.lib.hg_rgbuv_hist_workspace_bytes(ctypes.byref(_params(L, **kw)), ctypes.byref(f), ctypes.byref(b))
              for kw in bad]
     assert codes[0] == -2 and codes[1] == -3 and all(c < 0 for c in codes)
+
+
+def test_abi_guard_rejects_stale_or_unfilled_structs(L):
+    """hg_hist_params.struct_size (version 102): a caller compiled against another layout, or one that did not fill the
+    field in, is rejected before anything reads proj_cache / pre_relu; a garbage pre_relu or a misaligned cache pointer
+    is rejected too."""
+    f, b = ctypes.c_size_t(), ctypes.c_size_t()
+    q = lambda **kw: L.lib.hg_rgbuv_hist_workspace_bytes(ctypes.byref(_params(L, **kw)), ctypes.byref(f), ctypes.byref(b))
+    assert L.lib.hg_version() >= 102
+    assert q() == 0
+    assert q(struct_size=0) == -1 and q(struct_size=ctypes.sizeof(L.HgHistParams) - 16) == -1
+    assert q(pre_relu=7) == -1 and q(proj_cache=0x1004) == -1 and q(proj_cache=0x1000) == 0
+
+
+def test_proj_cache_query(L):
+    """The 32 B / pixel projection cache is only wanted by the dense MFMA kernels."""
+    use = lambda **kw: L.lib.hg_rgbuv_hist_uses_proj_cache(ctypes.byref(_params(L, **kw)))
+    assert use() == 1                                    # inverse-quadratic: dense
+    assert use(method=0) == 0                            # thresholding: scatter path
+    assert use(method=1, sigma=0.02) == 0                # narrow RBF: truncated scatter / gather pair
+    assert use(method=1, sigma=0.5) == 1                 # wide RBF: dense
+    assert use(method=9) == -2
 
 
 def test_null_pointers_rejected_before_any_launch(L):

@@ -111,3 +111,24 @@ def test_histogram_cache_is_bounded_in_bytes(folder):
     for _ in range(6):
         next(src)
     assert len(src.cache) == 3 and src.cache_bytes == 3 * one
+
+
+# ---- parity with the reference Dataset's image transform (golden: tests/golden/make_golden_dataset.py) -------------
+def test_item_images_equal_the_reference_dataset_transform():
+    """`Dataset.__getitem__(i)['images']` of the UNMODIFIED reference class (histoGAN/histoGAN.py:270-303: Resize(256) with
+    torchvision's truncating size arithmetic, CenterCrop with its half-to-even offsets, ToTensor) on the shipped target
+    images incl. the 799 x 533 one: `_load_rgb` reproduces every pixel exactly."""
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, 'dataset.npz'))
+    S = int(g['ds_meta'][0])
+    for i, name in enumerate(g['ds_paths']):
+        img = _load_rgb(os.path.join(GOLDEN_DIR, 'dataset_images', str(name)), S)
+        want = torch.from_numpy(g[f'ds_item{i}_images_u8']).float().div(255)
+        assert img.shape == want.shape and torch.equal(img, want), name
+
+
+def test_folder_order_matches_the_golden_index():
+    from conftest import GOLDEN_DIR
+    g = np.load(os.path.join(GOLDEN_DIR, 'dataset.npz'))
+    fd = FolderData(os.path.join(GOLDEN_DIR, 'dataset_images'), FakeHist(), 2, 64, torch.device('cpu'))
+    assert [p.name for p in fd.paths] == [str(n) for n in g['ds_paths']]

@@ -51,15 +51,54 @@ def test_graph_auto_mode_decides_and_trains(gpu_device, tmp_path):
 def test_graph_is_dropped_when_the_model_is_rebuilt(gpu_device, tmp_path):
     """load() rebuilds the GAN (load_config -> init_GAN): a graph captured on the old buffers must not be replayed."""
     tr, g = _run('1', 9, tmp_path)
-    assert g >= 2 and tr._graphs
+    assert g >= 2 and tr._graphs and {k[0] for k in tr._graphs} == {False, True}
     tr.save(0)
     old_ptr = tr.GAN._flat_g.data.data_ptr()
     tr.load(0)
-    assert '_graphs' not in tr.__dict__ and tr.GAN._flat_g.data.data_ptr() != old_ptr or True
+    assert '_graphs' not in tr.__dict__ and '_graph' not in tr.__dict__     # (the allocator may or may not reuse the address)
+    del old_ptr
     tr.steps = 9
     before = tr.GAN._flat_g.data.clone()
     for _ in range(3):
         tr.train(alpha=2)                      # captures anew on the new buffers and trains them
     assert tr.last_step_graphed and not torch.equal(before, tr.GAN._flat_g.data)
+    import math
+    assert all(math.isfinite(v) for v in (tr.d_loss, tr.g_loss, tr.h_loss))
+
+
+def test_graph_cache_is_keyed_on_alpha(gpu_device, tmp_path):
+    """alpha (the Hellinger weight) is a host scalar baked into the captured launches: another value must capture its own
+    graph, not replay the old one."""
+    tr, g = _run('1', 8, tmp_path)
+    n0 = len(tr._graphs)
+    tr.steps = 9
+    tr.train(alpha=2)
+    assert len(tr._graphs) == n0
+    h2 = tr.h_loss
+    tr.steps = 9
+    tr.train(alpha=4)
+    assert len(tr._graphs) == n0 + 1 and (False, 4.0, 2) in tr._graphs
+    assert tr.h_loss > 1.5 * h2            # the histogram loss scales with alpha (same weights up to one step)
+
+
+def test_failed_capture_falls_back_to_a_working_eager_step(gpu_device, tmp_path, monkeypatch):
+    """A capture error in the G phase (after D's parameters were frozen) must leave the trainer able to run the step
+    eagerly: requires_grad restored, gradient buffers reset."""
+    import histogan_amd.trainer as T
+    tr, g = _run('1', 6, tmp_path)         # six eager steps; the next plain step would capture
+    calls = {'n': 0}
+    real = T.hellinger_loss
+
+    def boom(*a, **k):
+        calls['n'] += 1
+        if calls['n'] == 1:
+            raise RuntimeError('injected: not capturable')
+        return real(*a, **k)
+    monkeypatch.setattr(T, 'hellinger_loss', boom)
+    tr.steps = 9
+    tr.train(alpha=2)                      # capture fails inside the G phase -> eager retry of the same step
+    assert tr._graph_failed and calls['n'] == 2
+    assert all(p.requires_grad for p in tr.GAN.D.parameters())
+    tr.train(alpha=2)
     import math
     assert all(math.isfinite(v) for v in (tr.d_loss, tr.g_loss, tr.h_loss))

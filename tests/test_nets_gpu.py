@@ -167,42 +167,13 @@ def test_diffgrad_and_ema_match_oracle(gpu_device):
 
 
 # ---- whole train step vs the oracle ------------------------------------------------------------
-class _ReplayRng:
-    """Feeds Trainer.train the tensors the oracle step uses (same draw order as the reference)."""
-
-    def __init__(self, device, B, L, LAT, S, seed):
-        g = torch.Generator().manual_seed(seed)
-        self.dev = device
-        self.z = [torch.randn(B, LAT, generator=g) for _ in range(4)]
-        self.img_noise = [torch.rand(B, S, S, 1, generator=g) for _ in range(2)]
-        self.pl = torch.randn(B, L - 2, LAT, generator=g)
-        self.zi = self.ni = 0
-        self.tt = 1
-
-    def noise(self, n, d):
-        z = self.z[self.zi]; self.zi += 1
-        return z.to(self.dev)
-
-    def noise_list(self, n, layers, d):
-        return [(self.noise(n, d), layers)]
-
-    def mixed_list(self, n, layers, d):
-        return self.noise_list(n, self.tt, d) + self.noise_list(n, layers - self.tt, d)
-
-    def image_noise(self, n, s):
-        x = self.img_noise[self.ni]; self.ni += 1
-        return x.to(self.dev)
-
-    def randn_like(self, t):
-        return self.pl.to(self.dev)
-
-
 def test_train_step_matches_oracle(gpu_device, tmp_path):
-    """One Trainer.train() step at step 0 (gradient penalty AND path-length regulariser active) against
-    the same step evaluated with oracle/ (functional nets + oracle histogram + oracle DiffGrad) on CPU."""
+    """One Trainer.train() step at step 0 (gradient penalty AND path-length regulariser active) against the same step
+    evaluated with oracle/ (functional nets + oracle histogram + oracle DiffGrad, tests/oracle_step.py) on the CPU in
+    fp32 (the reference's numerics) and in fp64 (truth).  The C3-shape version is tests/test_c3_parity_gpu.py."""
     from histoGAN import Trainer
-    from oracle import histogan_nets as N
     from oracle import rgbuv_hist as OH
+    from oracle_step import ReplayRng, oracle_train_step
     torch.manual_seed(11)
     S_, CAP, B, HB, ALPHA, LR = 32, 4, 2, 16, 2.0, 2e-4
     tr = Trainer('t', tmp_path / 'r', tmp_path / 'm', S_, CAP, batch_size=B, lr=LR, hist_bin=HB, hist_insz=150,
@@ -222,80 +193,40 @@ def test_train_step_matches_oracle(gpu_device, tmp_path):
         hist = OH.rgbuv_hist(torch.rand(B, 3, S_, S_, generator=gen), h=HB)
         batches.append({'images': img, 'histograms': hist})
     tr.loader = iter([{k: v.to(gpu_device) for k, v in b.items()} for b in batches])
-    rr = _ReplayRng(gpu_device, B, L, LAT, S_, 77)
-    tr.rng = rr
+    tr.rng = ReplayRng(gpu_device, B, L, LAT, S_, 77)
     tr.train(alpha=ALPHA)
     new = {k: v.detach().cpu() for k, v in GAN.state_dict().items()}
 
-    # ---- oracle step on CPU
-    rc = _ReplayRng(torch.device('cpu'), B, L, LAT, S_, 77)
-    sub = lambda p: {k[len(p) + 1:]: sd0[k].clone().requires_grad_(True) for k in sd0 if k.startswith(p + '.')}
-    sG, sD, sS, sH = sub('G'), sub('D'), sub('S'), sub('H')
-    nblk = L + 1
-
-    def w_hw(style, hist):
-        w = [(N.vectorizer(sS, z, 'net'), n) for z, n in style]
-        hw = N.vectorizer(sH, hist, 'fcs')[:, None, :]
-        return N.styles_def_to_tensor(w), torch.cat((hw, hw), 1)
-
-    # D phase
-    style = rc.mixed_list(B, L - 2, LAT); noise = rc.image_noise(B, S_)
-    img = batches[0]['images'].clone().requires_grad_(True)
-    with torch.no_grad():
-        w, hw = w_hw(style, batches[0]['histograms'])
-        fake = N.generator(sG, w, hw, noise, L)
-    real_out = N.discriminator(sD, img, nblk)
-    fake_out = N.discriminator(sD, fake, nblk)
-    div = (F.relu(1 + real_out) + F.relu(1 - fake_out)).mean()
-    d_loss = div + N.gradient_penalty(img, real_out)
-    dk = list(sD.keys())
-    dgr = torch.autograd.grad(d_loss, [sD[k] for k in dk])
-    for k, gr in zip(dk, dgr):
-        st = dict(step=0, exp_avg=torch.zeros_like(gr), exp_avg_sq=torch.zeros_like(gr), previous_grad=torch.zeros_like(gr))
-        with torch.no_grad():
-            N.diffgrad_step(sD[k], gr, st, lr=LR, betas=(0.5, 0.9))
-    # G phase (uses the UPDATED discriminator)
-    style = rc.mixed_list(B, L - 2, LAT); noise = rc.image_noise(B, S_)
-    w, hw = w_hw(style, batches[1]['histograms'])
-    gen_img = N.generator(sG, w, hw, noise, L)
-    fo = N.discriminator(sD, gen_img, nblk)
-    gh = OH.rgbuv_hist(F.relu(gen_img), h=HB)
-    h_loss = OH.hellinger_loss(batches[1]['histograms'], gh, ALPHA)
-    g_loss = fo.mean() + h_loss
-    std = 0.1 / (w.std(dim=0, keepdim=True) + 1e-8)
-    w2 = w + rc.randn_like(w) / (std + 1e-8)
-    pl = ((N.generator(sG, w2, hw, noise, L) - gen_img) ** 2).mean(dim=(1, 2, 3))
-    g_loss = g_loss + ((pl - 0) ** 2).mean()
-    groups = [('G', sG), ('S', sS), ('H', sH)]
-    keys = [(p, k) for p, s in groups for k in s]
-    ggr = torch.autograd.grad(g_loss, [dict(groups)[p][k] for p, k in keys])
-    for (p, k), gr in zip(keys, ggr):
-        st = dict(step=0, exp_avg=torch.zeros_like(gr), exp_avg_sq=torch.zeros_like(gr), previous_grad=torch.zeros_like(gr))
-        with torch.no_grad():
-            N.diffgrad_step(dict(groups)[p][k], gr, st, lr=LR, betas=(0.5, 0.9))
-
-    assert abs(tr.d_loss - float(div)) <= 1e-4
-    assert abs(tr.g_loss - float(fo.mean())) <= 1e-4
-    assert abs(tr.h_loss - float(h_loss)) <= 1e-4
-    # generator-side gradients are still in the flat buffer (zeroed at the start of the next step)
-    for (p, k), gr in zip(keys, ggr):
-        mine = dict(getattr(GAN, p).named_parameters())[k].grad.detach().cpu().numpy()
-        # 3e-3 (measured worst tensor: 1.1e-3).  The histogram's own per-pixel gradient matches the reference at 1e-4
-        # on generator-like images incl. every clamp-edge pixel (tests/test_hist_big_gpu.py, golden trainer_2x256to150);
-        # what is left here is that two fp32 evaluations of the GENERATOR differ by ~1e-7, and d hist / d x =
-        # .../(x + 1e-6) turns that into a several-% change of the gradient of the few pixels within ~1e-5 of the
-        # relu/clamp edge, which every parameter gradient sums over.
-        assert relmax(mine, gr.numpy()) <= 3e-3, (p, k)
+    cpu = torch.device('cpu')
+    ref = oracle_train_step(sd0, batches, ReplayRng(cpu, B, L, LAT, S_, 77), L, HB, ALPHA, LR, True, True)
+    truth = oracle_train_step(sd0, batches, ReplayRng(cpu, B, L, LAT, S_, 77, dtype=torch.float64), L, HB, ALPHA, LR,
+                              True, True)
+    assert abs(tr.d_loss - ref['d_loss']) <= 1e-4
+    assert abs(tr.g_loss - ref['g_loss']) <= 1e-4
+    assert abs(tr.h_loss - ref['h_loss']) <= 1e-4
+    assert abs(tr.last_gp_loss - ref['gp']) <= 1e-4 * max(1.0, abs(ref['gp']))
+    # Generator-side gradients (still in the flat buffer; zeroed at the start of the next step), SURVEY 8(c) criterion:
+    # our distance to the fp64 evaluation within 2x the fp32 reference's own.  (Round 2 asserted 3e-3 against the fp32
+    # oracle and explained it by the histogram's 1 / (x + 1e-6) gradient at relu / clamp-edge pixels amplifying 1e-7
+    # differences of the generator output; measured here, both fp32 evaluations sit equally far from the truth.)
+    gkeys = [pk for pk in truth['grads'] if pk[0] != 'D']
+    tn = torch.cat([truth['grads'][pk].flatten() for pk in gkeys]).norm()
+    mine = {pk: dict(getattr(GAN, pk[0]).named_parameters())[pk[1]].grad.detach().cpu().double() for pk in gkeys}
+    d_ours = float(torch.cat([(mine[pk] - truth['grads'][pk]).flatten() for pk in gkeys]).norm() / tn)
+    d_ref = float(torch.cat([(ref['grads'][pk].double() - truth['grads'][pk]).flatten() for pk in gkeys]).norm() / tn)
+    assert d_ours <= 2 * d_ref + 1e-7, (d_ours, d_ref)
+    for pk in gkeys:
+        e_o = relmax(mine[pk].numpy(), truth['grads'][pk].numpy())
+        e_r = relmax(ref['grads'][pk].numpy(), truth['grads'][pk].numpy())
+        assert e_o <= max(1e-4, 3 * e_r), (pk, e_o, e_r)
     # parameters after the step.  The first DiffGrad step is ~ lr*sigmoid(|g|)*g/(|g|+3e-8): compare the
     # deltas where the gradient is not rounding noise (elsewhere the sign itself is ill-conditioned)
-    for (p, s), grads in ((('D', sD), dict(zip(dk, dgr))),) + tuple(
-            ((p, s), {k: gr for (pp, k), gr in zip(keys, ggr) if pp == p}) for p, s in groups):
-        for k, v in s.items():
-            gr = grads[k].numpy()
-            mask = np.abs(gr) > 5e-2 * np.abs(gr).max()   # well above the gradient tolerance: sign is certain
-            dn = (new[f'{p}.{k}'] - sd0[f'{p}.{k}']).numpy()
-            do = (v.detach() - sd0[f'{p}.{k}']).numpy()
-            assert np.max(np.abs(dn - do)[mask]) <= 0.02 * LR, (p, k)
+    for (p, k), v in ref['params'].items():
+        gr = ref['grads'][(p, k)].numpy()
+        mask = np.abs(gr) > 5e-2 * np.abs(gr).max()   # well above the gradient tolerance: sign is certain
+        dn = (new[f'{p}.{k}'] - sd0[f'{p}.{k}']).numpy()
+        do = (v - sd0[f'{p}.{k}']).numpy()
+        assert np.max(np.abs(dn - do)[mask]) <= 0.02 * LR, (p, k)
 
 
 @pytest.mark.parametrize('shape', [(3, 5, 4, 4), (2, 16, 64, 64), (7, 3, 5, 9), (1, 1, 1, 1), (4, 130, 8, 8)])

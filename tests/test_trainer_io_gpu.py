@@ -78,13 +78,17 @@ def test_transparent_rgba_steps(gpu_device, tmp_path):
     assert tr.evaluate(num=None).shape[1] == 4
 
 
-def test_nan_recovery_raises_nanexception(gpu_device, tmp_path):
+@pytest.mark.parametrize('lazy', [False, True])
+def test_nan_recovery_raises_nanexception(lazy, gpu_device, tmp_path):
     """Reference error convention (histoGAN/histoGAN.py:1002-1010): a NaN loss reloads the last checkpoint and raises
-    NanException from train()."""
+    NanException from train().  With the deferred read-back (lazy_stats, the default) the exception comes from the NEXT
+    train() call -- still inside the caller's `retry_call(model.train, exceptions=NanException)` loop -- or is armed as
+    soon as a statistic is read; with lazy_stats = False from the same call, as in the reference."""
     from histoGAN import NanException, Trainer
     tr = Trainer('nan', str(tmp_path / 'r'), str(tmp_path / 'm'), 32, 2, batch_size=2, hist_bin=16, hist_insz=32,
                  hist_resizing='interpolation', save_every=1000)
     tr.run_evaluate = False
+    tr.lazy_stats = lazy
     tr.set_synthetic_data_src()
     tr.train(alpha=2)                                    # step 0 writes checkpoint 0
     good = {k: v.clone() for k, v in tr.GAN.state_dict().items()}
@@ -92,6 +96,9 @@ def test_nan_recovery_raises_nanexception(gpu_device, tmp_path):
         tr.GAN.D.to_logit.weight.fill_(float('nan'))
     from histogan_amd.conv import weights_changed
     weights_changed()
+    if lazy:
+        tr.train(alpha=2)                                # the NaN step itself: its statistics are still in flight
+        assert not np.isfinite(tr.d_loss)                # reading one flushes them and arms the exception
     with pytest.raises(NanException):
         tr.train(alpha=2)
     # the checkpoint was reloaded: finite weights again (those of step 0's save), training continues

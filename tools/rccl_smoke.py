@@ -20,7 +20,7 @@ os.environ.setdefault('MASTER_PORT', '29533')
 dev = torch.device('cuda', local)
 torch.cuda.set_device(dev)
 dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-ddp.is_dist = lambda: True                     # exercise the collective code paths even at world size 1
+ddp.is_dist = lambda: True                     # exercise the collective code paths even at world size 1 (incl. ReduceOp.AVG)
 ps = [torch.nn.Parameter(torch.randn(1000, 1000, device=dev)), torch.nn.Parameter(torch.randn(77, device=dev))]
 flat = FlatParams(ps)
 ddp.broadcast_flat(flat)
