@@ -146,6 +146,11 @@ def cached(w, tag, compute):
     st = _stamp(w, owner)
     if hit is not None and hit[0] == st:
         return hit[1]
+    if tag == 'wsq' and PACK_MULTI and w.is_cuda and _pack_owner(owner, w.device):
+        # the batched packing launch of this weight's flat buffer also leaves sum_taps W^2 of every weight (hg_pack_item.wsq)
+        hit = _cache.get((key, tag))
+        if hit is not None and hit[0] == st:
+            return hit[1]
     val = compute(w)
     _cache[(key, tag)] = (st, val)
     return val
@@ -180,7 +185,8 @@ _multi = {}          # owner -> dict(sig, keys, bufs, table, n, blocks): the bat
 
 class _PackItem(ctypes.Structure):       # include/hg_conv.h: hg_pack_item
     _fields_ = [('w', ctypes.c_void_p), ('wt_fwd', ctypes.c_void_p), ('wt_dgrad', ctypes.c_void_p),
-                ('Co', ctypes.c_int32), ('Ci', ctypes.c_int32), ('ksize', ctypes.c_int32), ('block_begin', ctypes.c_int32)]
+                ('Co', ctypes.c_int32), ('Ci', ctypes.c_int32), ('ksize', ctypes.c_int32), ('block_begin', ctypes.c_int32),
+                ('wsq', ctypes.c_void_p)]
 
 
 def build_pack_plans(device):
@@ -213,8 +219,10 @@ def _pack_owner(owner, device, launch=True):
                 Co, Ci, k, _ = p.shape
                 wf = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_FWD), dtype=torch.float32, device=device)
                 wd = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_DGRAD), dtype=torch.float32, device=device)
-                bufs[key] = (wf, wd)
-                items[i] = _PackItem(p.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, blocks)
+                # sum over the taps of W^2 (the demodulation coefficient's weight factor), from the same tile
+                wq = torch.empty((Co, Ci), dtype=torch.float32, device=device)
+                bufs[key] = (wf, wd, wq)
+                items[i] = _PackItem(p.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, blocks, wq.data_ptr())
                 blocks += lib.hg_conv_pack_blocks(Co, Ci)
             raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).clone()
             plan = _multi[owner] = dict(sig=sig, bufs=bufs, table=raw.to(device), n=len(live), blocks=blocks)
@@ -224,9 +232,10 @@ def _pack_owner(owner, device, launch=True):
               'hg_conv_pack_weights_multi')
     for key, p in live:
         st = _stamp(p, owner)
-        wf, wd = plan['bufs'][key]
+        wf, wd, wq = plan['bufs'][key]
         _cache[(key, PACK_FWD)] = (st, wf)
         _cache[(key, PACK_DGRAD)] = (st, wd)
+        _cache[(key, 'wsq')] = (st, wq)
     return True
 
 
@@ -283,6 +292,34 @@ def conv_fwd_packed(x, wt, N, ksize, stride=1, iscale=None, oscale=None, bias=No
         check(lib.hg_conv2d_fwd(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(iscale), _ptr(oscale), _ptr(bias),
                                 B, K, N, H, W, ksize, stride, _ptr(ws), nb, _st(x)), 'hg_conv2d_fwd')
     return out
+
+
+def conv_fwd_add_packed(x, wt, N, ksize, addend, bias=None, stride=1):
+    """out = (conv(x, Wt) + bias[n]) + addend   (addend (B,N,Ho,Wo) contiguous: hg_conv2d_fwd_add)."""
+    B, K, H, W = x.shape
+    with on_device(x.device):
+        out = torch.empty((B, N, _out_size(H, stride), _out_size(W, stride)), dtype=torch.float32, device=x.device)
+        if addend.shape != out.shape:
+            raise ValueError(f'conv2d_add: addend {tuple(addend.shape)} does not match the output {tuple(out.shape)}')
+        nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, stride, 0)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
+        check(lib.hg_conv2d_fwd_add(x.data_ptr(), wt.data_ptr(), out.data_ptr(), addend.data_ptr(), _ptr(bias),
+                                    B, K, N, H, W, ksize, stride, _ptr(ws), nb, _st(x)), 'hg_conv2d_fwd_add')
+    return out
+
+
+def lrelu_bwd_channel_sum(g, out, slope, want_sum=True):
+    """(g * (out > 0 ? 1 : slope), its per-channel sum or None) in one pass (hg_lrelu_bwd_channel_sum)."""
+    g, out = _f32c(g), _f32c(out)
+    B, C, H, W = g.shape
+    with on_device(g.device):
+        gm = torch.empty_like(g)
+        cs = torch.empty(C, dtype=torch.float32, device=g.device) if want_sum else None
+        nb = lib.hg_nets_workspace_bytes(B, C, H, W)
+        ws = torch.empty(max(nb, 4), dtype=torch.uint8, device=g.device)
+        check(lib.hg_lrelu_bwd_channel_sum(g.data_ptr(), out.data_ptr(), float(slope), gm.data_ptr(), _ptr(cs), B, C, H * W,
+                                           ws.data_ptr(), ws.numel(), _st(g)), 'hg_lrelu_bwd_channel_sum')
+    return gm, cs
 
 
 def conv_dgrad_packed(g, wt, N, H, W, ksize, stride=1, iscale=None, oscale=None):
@@ -503,20 +540,54 @@ class _ConvLrelu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, w, out = ctx.saved_tensors
-        gm = torch.ops.aten.leaky_relu_backward(g, out, ctx.slope, True)
         gx = gw = gb = None
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2] and not _skip_wgrad
+        if torch.is_grad_enabled():      # a graph of this backward is being recorded (gradient penalty): differentiable ops
+            gm = torch.ops.aten.leaky_relu_backward(g, out, ctx.slope, True)
+            if want_gb:
+                gb = gm.sum(dim=(0, 2, 3))
+        else:                            # plain backward: the mask and the bias gradient from ONE pass over (g, out)
+            gm, gb = lrelu_bwd_channel_sum(g, out, ctx.slope, want_gb)
         if ctx.needs_input_grad[0]:
             gx = _ConvDgrad.apply(gm, w, x.shape[2], x.shape[3], ctx.stride)
         if not _skip_wgrad:
             if ctx.needs_input_grad[1] and not _direct_wgrad(w, x, gm, ctx.stride):
                 gw = _ConvWgrad.apply(gm, x, w.shape[2], ctx.stride)
+        return gx, gw, gb, None, None
+
+
+class _ConvAdd(torch.autograd.Function):
+    """y = (conv(x, w) + bias) + addend in ONE launch: the residual sum of DiscriminatorBlock.forward
+    (`x = self.net(x); x = x + res`, histoGAN/histoGAN.py:520-524) in the epilogue of the 1x1 `conv_res` launch.
+    Bilinear part as _Conv (differentiable to any order), the addend's gradient is the incoming one."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, addend, stride):
+        _check_args(x, w, stride)
+        if x.shape[1] != w.shape[1]:
+            raise ValueError(f'conv2d: x {tuple(x.shape)} does not match w {tuple(w.shape)}')
+        ctx.save_for_backward(x, w)
+        ctx.stride, ctx.has_bias = stride, bias is not None
+        xc, wc = _f32c(x), _f32c(w)
+        bc = None if bias is None else _f32c(bias)
+        return conv_fwd_add_packed(xc, pack_weights(wc, PACK_FWD), w.shape[0], w.shape[2], _f32c(addend), bc, stride)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _ConvDgrad.apply(g, w, x.shape[2], x.shape[3], ctx.stride)
+        if not _skip_wgrad:
+            if ctx.needs_input_grad[1] and not _direct_wgrad(w, x, g, ctx.stride):
+                gw = _ConvWgrad.apply(g, x, w.shape[2], ctx.stride)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 if torch.is_grad_enabled():
-                    gb = gm.sum(dim=(0, 2, 3))
+                    gb = g.sum(dim=(0, 2, 3))
                 else:
                     from .ops import channel_sum
-                    gb = channel_sum(gm)
-        return gx, gw, gb, None, None
+                    gb = channel_sum(g)
+        return gx, gw, gb, (g if ctx.needs_input_grad[3] else None), None
 
 
 _I32 = 2 ** 31 - 1
@@ -550,6 +621,13 @@ def conv2d_lrelu(x, w, bias=None, slope=0.2):
 def conv2d(x, w, bias=None, stride=1):
     """F.conv2d(x, w, bias, stride=stride, padding=k//2) for k in {1,3} on the MFMA implicit-GEMM kernels."""
     return _sliced(lambda t: _Conv.apply(t, w, bias, stride), x, w, stride)
+
+
+def conv2d_add(x, w, bias, addend, stride=1):
+    """F.conv2d(x, w, bias, stride, padding=k//2) + addend as one launch."""
+    if _batch_pieces(x, w, stride) != 1 or _use_b6(x.shape[1], w.shape[0], x.shape[2], x.shape[3], x.shape[0], w.shape[2], stride):
+        return conv2d(x, w, bias, stride) + addend
+    return _ConvAdd.apply(x, w, bias, addend, stride)
 
 
 def conv2d_same(x, w, bias=None):

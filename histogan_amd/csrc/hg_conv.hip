@@ -67,6 +67,7 @@ struct ConvArgs {
   const float *in, *wt;
   float *out;
   const float *iscale, *oscale, *bias;
+  const float *addend;   // optional, out layout: out = conv + bias + addend (the discriminator block's residual sum)
   int B, K, N, Kp, Np;
   int Hi, Wi;      // input image
   int Ho, Wo;      // output image
@@ -381,6 +382,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, con
           if (ch < N) {
             float v = acc[i][j][r];
             if (fin && a.bias) v += a.bias[ch];
+            if (fin && a.addend) v += a.addend[pofs + (size_t)ch * HWo];
             ob[(size_t)ch * HWo] = v;
           }
         }
@@ -458,8 +460,8 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv_parity4(cons
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__ slab, float *__restrict__ out,
                                                        const float *__restrict__ oscale, const float *__restrict__ bias,
                                                        const float *__restrict__ noise_w, const float *__restrict__ noise_img,
-                                                       int noise_S, float slope, long long total, int HWo, int Wo, int N,
-                                                       int ksplit) {
+                                                       const float *__restrict__ addend, int noise_S, float slope,
+                                                       long long total, int HWo, int Wo, int N, int ksplit) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     float v = 0.f;
     for (int z = 0; z < ksplit; ++z) v += slab[(size_t)z * total + i];
@@ -471,6 +473,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float *__restrict__
       add = fmaf(noise_w[n], noise_img[((size_t)(bn / N) * noise_S + y) * noise_S + x], add);
     }
     v = oscale ? fmaf(v, oscale[bn], add) : v + add;
+    if (addend) v += addend[i];
     if (slope > 0.f) v = v > 0.f ? v : slope * v;
     out[i] = v;
   }
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(256) void k_pack(const float *__restrict__ w, float
 template <int TAPS>
 __device__ __forceinline__ void pack_both_tile(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wd,
                                                int Co, int Ci, int Kpf, int Npf, int Kpd, int Npd, int bx, int by,
-                                               float *tile_mem) {
+                                               float *tile_mem, float *__restrict__ wsq = nullptr) {
   constexpr int RW = 32 * TAPS;
   float(*tile)[RW + 1] = reinterpret_cast<float(*)[RW + 1]>(tile_mem);
   const int ci0 = bx * 32, co0 = by * 32;
@@ -872,6 +875,17 @@ __device__ __forceinline__ void pack_both_tile(const float *__restrict__ w, floa
     tile[e / RW][e % RW] = v[it];
   }
   __syncthreads();
+  if (wsq != nullptr) {   // sum of squares over the taps of every (co, ci) of the tile (fixed tap order)
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+      const int i = e >> 5, j = e & 31;
+      if (co0 + i < Co && ci0 + j < Ci) {
+        float q = 0.f;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) q = fmaf(tile[i][j * TAPS + t], tile[i][j * TAPS + t], q);
+        wsq[(size_t)(co0 + i) * Ci + ci0 + j] = q;
+      }
+    }
+  }
 #pragma unroll 4
   for (int e = threadIdx.x; e < 32 * RW; e += 256) {
     const int b = e & 31, a_ = (e >> 5) & 31, t = e >> 10;
@@ -904,8 +918,8 @@ __global__ __launch_bounds__(256) void k_pack_multi(const hg_pack_item *__restri
   const int Kpf = (im.Ci + 15) / 16 * 16, Npf = (im.Co + 127) / 128 * 128, Kpd = (im.Co + 15) / 16 * 16, Npd = (im.Ci + 127) / 128 * 128;
   const int gx = Npd / 32;
   const int bx = local % gx, by = local / gx;
-  if (im.ksize == 3) pack_both_tile<9>(im.w, im.wt_fwd, im.wt_dgrad, im.Co, im.Ci, Kpf, Npf, Kpd, Npd, bx, by, tile_mem);
-  else pack_both_tile<1>(im.w, im.wt_fwd, im.wt_dgrad, im.Co, im.Ci, Kpf, Npf, Kpd, Npd, bx, by, tile_mem);
+  if (im.ksize == 3) pack_both_tile<9>(im.w, im.wt_fwd, im.wt_dgrad, im.Co, im.Ci, Kpf, Npf, Kpd, Npd, bx, by, tile_mem, im.wsq);
+  else pack_both_tile<1>(im.w, im.wt_fwd, im.wt_dgrad, im.Co, im.Ci, Kpf, Npf, Kpd, Npd, bx, by, tile_mem, im.wsq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1196,7 +1210,7 @@ inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st) {
   long long nb = (total + 255) / 256;
   if (nb > 4096) nb = 4096;
   hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)nb), dim3(256), 0, st, a.slab, a.out, a.oscale, a.bias, a.noise_w,
-                     a.noise_img, a.noise_S, a.slope, total, a.Ho * a.Wo, a.Wo, a.N, ksplit);
+                     a.noise_img, a.addend, a.noise_S, a.slope, total, a.Ho * a.Wo, a.Wo, a.N, ksplit);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
@@ -1471,13 +1485,15 @@ int hg_conv_pack_weights_both(const float *w, float *wt_fwd, float *wt_dgrad, in
 static int conv2d_fwd_impl(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
                            const float *bias, const float *noise_w, const float *noise_img, int32_t noise_S,
                            float lrelu_slope, int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
-                           int32_t stride, void *workspace, size_t workspace_bytes, void *stream) {
+                           int32_t stride, void *workspace, size_t workspace_bytes, void *stream,
+                           const float *addend = nullptr) {
   if (!in || !wt || !out || !conv_args_ok(B, K, N, Hi, Wi, ksize, stride)) return HG_EINVAL;
+  if (addend && (iscale || oscale || noise_img || lrelu_slope > 0.f)) return HG_EINVAL;   // plain (bias-only) epilogue only
   if ((noise_img != nullptr) != (noise_w != nullptr) || lrelu_slope < 0.f) return HG_EINVAL;
   if (noise_img && (noise_S < out_size(Hi, stride) || noise_S < out_size(Wi, stride))) return HG_EINVAL;
   if (!fits_i32(B, K, N, Hi, Wi)) return HG_EUNSUPPORTED;
   ConvArgs a;
-  a.in = in; a.wt = wt; a.out = out; a.iscale = iscale; a.oscale = oscale; a.bias = bias;
+  a.in = in; a.wt = wt; a.out = out; a.iscale = iscale; a.oscale = oscale; a.bias = bias; a.addend = addend;
   a.noise_w = noise_w; a.noise_img = noise_img; a.noise_S = noise_S; a.slope = lrelu_slope;
   a.B = B; a.K = K; a.N = N; a.Hi = Hi; a.Wi = Wi;
   a.Ho = a.Hc = out_size(Hi, stride); a.Wo = a.Wc = out_size(Wi, stride);
@@ -1502,6 +1518,14 @@ int hg_conv2d_fwd(const float *in, const float *wt, float *out, const float *isc
                          workspace, workspace_bytes, stream);
 }
 
+int hg_conv2d_fwd_add(const float *in, const float *wt, float *out, const float *addend, const float *bias, int32_t B,
+                      int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+  if (!addend) return HG_EINVAL;
+  return conv2d_fwd_impl(in, wt, out, nullptr, nullptr, bias, nullptr, nullptr, 0, 0.f, B, K, N, Hi, Wi, ksize, stride,
+                         workspace, workspace_bytes, stream, addend);
+}
+
 int hg_modconv2d_fwd(const float *in, const float *wt, float *out, const float *iscale, const float *oscale,
                      const float *bias, const float *noise_w, const float *noise_img, int32_t noise_S,
                      float lrelu_slope, int32_t B, int32_t K, int32_t N, int32_t H, int32_t W, int32_t ksize,
@@ -1517,7 +1541,7 @@ int hg_conv2d_dgrad(const float *gout, const float *wt, float *gin, const float 
   if (!fits_i32(B, K, N, Hi, Wi)) return HG_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   ConvArgs a;
-  a.in = gout; a.wt = wt; a.out = gin; a.iscale = iscale; a.oscale = oscale; a.bias = nullptr;
+  a.in = gout; a.wt = wt; a.out = gin; a.iscale = iscale; a.oscale = oscale; a.bias = nullptr; a.addend = nullptr;
   a.noise_w = a.noise_img = nullptr; a.noise_S = 0; a.slope = 0.f;
   a.B = B; a.K = K; a.N = N;
   a.Hi = out_size(Hi, stride); a.Wi = out_size(Wi, stride);  // the kernel's input is grad_out

@@ -309,6 +309,44 @@ __global__ __launch_bounds__(256) void k_channel_sum(const float *__restrict__ g
   if (threadIdx.x == 0) part[(size_t)c * gridDim.x + blockIdx.x] = acc;
 }
 
+// gm = g * (out > 0 ? 1 : slope) (the gradient through LeakyReLU, decided on the OUTPUT: sign(out) == sign(pre-activation))
+// and the per-channel sum of gm (the bias gradient of the convolution in front of it) from the same pass.
+// grid = (chunks, C), partials + k_plane_sum_finish as k_channel_sum.
+__global__ __launch_bounds__(256) void k_lrelu_bwd_csum(const float *__restrict__ g, const float *__restrict__ out,
+                                                        float *__restrict__ gm, float *__restrict__ part, float slope,
+                                                        int B, int C, int HW) {
+  __shared__ float sm[4];
+  const int c = blockIdx.y;
+  float acc = 0.f;
+  const long long per = (long long)B * HW;
+  if ((HW & 3) == 0) {
+    const int hw4 = HW / 4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < per / 4; e += (long long)gridDim.x * 256) {
+      const long long b = e / hw4, p4 = e - b * hw4;
+      const size_t off = ((size_t)b * C + c) * HW;
+      const float4 v = reinterpret_cast<const float4 *>(g + off)[p4];
+      const float4 o = reinterpret_cast<const float4 *>(out + off)[p4];
+      float4 r;
+      r.x = o.x > 0.f ? v.x : v.x * slope; r.y = o.y > 0.f ? v.y : v.y * slope;
+      r.z = o.z > 0.f ? v.z : v.z * slope; r.w = o.w > 0.f ? v.w : v.w * slope;
+      reinterpret_cast<float4 *>(gm + off)[p4] = r;
+      acc += (r.x + r.y) + (r.z + r.w);
+    }
+  } else {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < per; e += (long long)gridDim.x * 256) {
+      const long long b = e / HW, p = e - b * HW;
+      const size_t off = ((size_t)b * C + c) * HW + p;
+      const float v = g[off], r = out[off] > 0.f ? v : v * slope;
+      gm[off] = r;
+      acc += r;
+    }
+  }
+  if (part) {
+    acc = block_sum<256>(acc, sm);
+    if (threadIdx.x == 0) part[(size_t)c * gridDim.x + blockIdx.x] = acc;
+  }
+}
+
 // ---- optimizer ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_diffgrad(float *__restrict__ p, const float *__restrict__ g,
                                                   float *__restrict__ m, float *__restrict__ v,
@@ -455,6 +493,22 @@ int hg_channel_sum(const float *g, float *out, int32_t B, int32_t C, int32_t HW,
   HG_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_plane_sum_finish, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)workspace, out, C, chunks);
   HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+int hg_lrelu_bwd_channel_sum(const float *g, const float *out, float slope, float *gm, float *csum, int32_t B, int32_t C,
+                             int32_t HW, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!g || !out || !gm || B <= 0 || C <= 0 || HW <= 0 || !(slope >= 0.f)) return HG_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = plane_chunks(C, (long long)B * HW / 4);
+  if (csum && (!workspace || workspace_bytes < (size_t)C * chunks * sizeof(float))) return HG_EWORKSPACE;
+  hipLaunchKernelGGL(k_lrelu_bwd_csum, dim3(chunks, C), dim3(256), 0, st, g, out, gm, csum ? (float *)workspace : nullptr,
+                     slope, B, C, HW);
+  HG_LAUNCH_CHECK();
+  if (csum) {
+    hipLaunchKernelGGL(k_plane_sum_finish, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)workspace, csum, C, chunks);
+    HG_LAUNCH_CHECK();
+  }
   return HG_OK;
 }
 

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from .conv import conv2d, conv2d_lrelu, conv2d_same
+from .conv import conv2d, conv2d_add, conv2d_lrelu, conv2d_same
 
 EPS = 1e-8  # histoGAN/histoGAN.py:53
 
@@ -242,14 +242,14 @@ class DiscriminatorBlock(nn.Module):
         self.downsample = Conv2d(filters, filters, 3, padding=1, stride=2) if downsample else None
 
     def forward(self, x):
-        res = self.conv_res(x)
         if x.is_cuda:
-            # conv + bias + LeakyReLU(0.2) as one launch each (== self.net(x): Conv2d, LeakyReLU, Conv2d, LeakyReLU)
-            x = conv2d_lrelu(x, self.net[0].weight, self.net[0].bias, 0.2)
-            x = conv2d_lrelu(x, self.net[2].weight, self.net[2].bias, 0.2)
+            # conv + bias + LeakyReLU(0.2) as one launch each (== self.net(x): Conv2d, LeakyReLU, Conv2d, LeakyReLU), and the
+            # residual sum `net(x) + conv_res(x)` in the epilogue of the 1x1 conv_res launch (same value: (conv + bias) + h)
+            h = conv2d_lrelu(x, self.net[0].weight, self.net[0].bias, 0.2)
+            h = conv2d_lrelu(h, self.net[2].weight, self.net[2].bias, 0.2)
+            x = conv2d_add(x, self.conv_res.weight, self.conv_res.bias, h)
         else:
-            x = self.net(x)
-        x = x + res
+            x = self.net(x) + self.conv_res(x)
         if self.downsample is not None:
             x = self.downsample(x)
         return x

@@ -346,6 +346,7 @@ class Trainer():
         for k in ('_graphs', '_graph', '_graph_pool', '_gs', '_gs_first'):
             self.__dict__.pop(k, None)
         self.__dict__.setdefault('_pending', []).clear()
+        self.__dict__.pop('_last_step_ev', None)
         args, kwargs = self.GAN_params
         self.GAN = HistoGAN(lr=self.lr, image_size=self.image_size, network_capacity=self.network_capacity,
                             transparent=self.transparent, fq_layers=self.fq_layers,
@@ -735,23 +736,20 @@ class Trainer():
             packed = torch.cat([stats, torch.zeros(1, dtype=stats.dtype, device=stats.device)])
         host = self._host_buffer()
         host.copy_(packed, non_blocking=True)
-        ev = torch.cuda.Event(enable_timing=self.keep_step_events)
+        ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         checkpoint_num = floor(self.steps / self.save_every)
         self._pending.append((ev, host, dict(step=self.steps, gp=apply_gradient_penalty, pl=apply_path_penalty,
-                                             checkpoint=checkpoint_num)))
+                                             checkpoint=checkpoint_num, host_ms=self.host_enqueue_ms,
+                                             prev_ev=self.__dict__.get('_last_step_ev'),
+                                             eager=not graphed)))
+        self._last_step_ev = ev
         if self.keep_step_events:
             self.step_events.append((self.steps, ev))
         will_save = self.run_save and self.steps % self.save_every == 0
         will_eval = self.run_evaluate and (self.steps % 1000 == 0 or (self.steps % 100 == 0 and self.steps < 2500))
         # save / evaluate look at this step's result (the reference checks for NaN before it saves, :1002-1014)
         self._drain(1 if (self.lazy_stats and not will_save and not will_eval) else 0, in_train=True)
-        if self.graph_mode == 'auto' and getattr(self, '_graph_auto', None) is None and self.steps >= 2 \
-                and not (apply_gradient_penalty or apply_path_penalty):
-            # eager plain step: share of its wall time (up to the read-back's return) the host spent enqueueing
-            self.__dict__.setdefault('_host_ratio', []).append(self.host_enqueue_ms / max((perf_counter() - t_host0) * 1e3, 1e-3))
-            if len(self._host_ratio) == 2 and self.is_main and os.environ.get('HG_VERBOSE'):
-                print(f'train step: HG_GRAPH=auto host-enqueue share {self._host_ratio} (graph above {GRAPH_AUTO_RATIO})')
 
         # moving averages (reference :996-1000)
         if self.steps % 10 == 0 and self.steps > 20000:
@@ -785,6 +783,15 @@ class Trainer():
             ev, host_t, meta = self._pending.pop(0)
             ev.synchronize()
             host = host_t.numpy().copy()
+            if self.graph_mode == 'auto' and self.__dict__.get('_graph_auto') is None and meta['eager'] \
+                    and meta['step'] >= 2 and not (meta['gp'] or meta['pl']) and meta['prev_ev'] is not None:
+                # HG_GRAPH=auto: the host's share of an eager plain step = its enqueue time over the GPU-side time between the
+                # end-of-step events of this step and the previous one (host-bound: the two are equal; GPU-bound: the host
+                # runs ahead).  Event times, not host wall times: with the deferred read-back the host's wall time of a
+                # call says when the PREVIOUS step finished.
+                gpu_ms = meta['prev_ev'].elapsed_time(ev)
+                self.__dict__.setdefault('_host_ratio', []).append(meta['host_ms'] / max(gpu_ms, 1e-3))
+            meta['prev_ev'] = None
             # generator loss incl. the histogram term and the gradient penalty, as the reference's checks on gen_loss /
             # disc_loss (:978, :925); under data parallelism the flag is the all-reduced one so every rank raises
             has_nan = bool(host[6] > 0 or np.isnan(host[:4]).any())

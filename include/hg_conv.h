@@ -45,6 +45,14 @@ int hg_conv2d_fwd(const float *in, const float *wt, float *out, const float *isc
                   const float *bias, int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize,
                   int32_t stride, void *workspace, size_t workspace_bytes, void *stream);
 
+/* out = conv(in) + bias + addend, addend (B,N,Ho,Wo) like out: the residual sum of a discriminator block
+ * (`x = self.net(x); x = x + res`, histoGAN/histoGAN.py:520-524) folded into the epilogue of its 1x1 `conv_res`
+ * launch -- (conv + bias) + addend in that order, i.e. bit-identical to the convolution followed by an add.
+ * No input / output scales.  Workspace as hg_conv2d_workspace_bytes(..., dgrad 0). */
+int hg_conv2d_fwd_add(const float *in, const float *wt, float *out, const float *addend, const float *bias, int32_t B,
+                      int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
 /* The generator's modulated convolution stage in ONE launch (Conv2DMod.forward + noise + LeakyReLU of
  * GeneratorBlock.forward, histoGAN/histoGAN.py:420-440 and :465-476), stride 1:
  *   out[b,n,y,x] = lrelu_slope( oscale[b,n] * sum_{k,dy,dx} iscale[b,k]*in[b,k,y+dy-p,x+dx-p]*Wt[dy*ksize+dx][k][n]
@@ -72,6 +80,10 @@ typedef struct hg_pack_item {
   const float *w;
   float *wt_fwd, *wt_dgrad;
   int32_t Co, Ci, ksize, block_begin;
+  /* optional (NULL: none): wsq[co][ci] = sum_taps W[co][ci][t]^2, (Co, Ci) contiguous -- the weight-only factor of the
+   * demodulation coefficient d[b,o] = rsqrt(sum_i (s[b,i]+1)^2 wsq[o][i] + 1e-8) (Conv2DMod, histoGAN/histoGAN.py:427-429),
+   * formed from the tile the packing already holds instead of a pow + reduce pass over every weight per step */
+  float *wsq;
 } hg_pack_item;
 int32_t hg_conv_pack_blocks(int32_t Co, int32_t Ci);
 int hg_conv_pack_weights_multi(const hg_pack_item *items_dev, int32_t n_items, int32_t total_blocks, void *stream);

@@ -57,6 +57,13 @@ int hg_demod_noise_lrelu_bwd(const float *gout, const float *out, const float *c
 int hg_channel_sum(const float *g, float *out, int32_t B, int32_t C, int32_t HW, void *workspace,
                    size_t workspace_bytes, void *stream);
 
+/* gm = g * (out > 0 ? 1 : slope): the gradient through `nn.Conv2d -> LeakyReLU(slope)` of a discriminator block
+ * (histoGAN/histoGAN.py:510-515), masked on the activation's OUTPUT (== aten leaky_relu_backward(g, out, slope, True)),
+ * and csum[c] = sum_{b,p} gm[b,c,p], the bias gradient of that convolution, from the same pass (csum may be NULL).
+ * g, out, gm (B, C, HW) contiguous; workspace as hg_channel_sum. */
+int hg_lrelu_bwd_channel_sum(const float *g, const float *out, float slope, float *gm, float *csum, int32_t B, int32_t C,
+                             int32_t HW, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Fused multi-tensor DiffGrad step over one flat parameter buffer of n floats:
  *   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  dfc = 1/(1+exp(-|g_prev-g|));  g_prev = g
  *   p -= lr*sqrt(1-b2^t)/(1-b1^t) * (m*dfc) / (sqrt(v)+eps)                         (t = step >= 1) */

@@ -46,10 +46,16 @@ class ReplayRng:
         return self._t(self.pl)
 
 
-def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hist_kw=None, optimizer=True):
+def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hist_kw=None, optimizer=True, d_override=None):
     """sd0: GAN.state_dict() before the step (any device / dtype; moved to rng's).  batches: [D-phase batch, G-phase
     batch] of {'images', 'histograms'}.  gp / pl: gradient-penalty / path-length step.  Returns a dict with the loss
-    values, the gradients {('D', name): g, ('G', name): g, ...} and (optimizer=True) the updated parameters."""
+    values, the gradients {('D', name): g, ('G', name): g, ...} and (optimizer=True) the updated parameters.
+    d_override: {name: tensor} discriminator parameters to use in the G phase INSTEAD of the oracle's own updated ones.
+    The first DiffGrad step moves every parameter by ~lr * sign(g): where a gradient is rounding noise its sign -- and with
+    it the parameter after the step -- is ill-conditioned, and at network_capacity 16 the 9e7 such +-lr choices shift the
+    (un-normalised, |logit| >> 1) discriminator output visibly.  Handing the G phase the discriminator the product path
+    actually used separates the two questions: the D update is checked on its own (masked parameter deltas), the G phase
+    against the same discriminator."""
     from oracle import histogan_nets as N
     from oracle import rgbuv_hist as OH
     dev, dt = rng.dev, rng.dtype
@@ -96,6 +102,9 @@ def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hi
     grads = {('D', k): g.detach() for k, g in zip(dk, dgr)}
     if optimizer:
         diffgrad({k: sD[k] for k in dk}, dgr)
+    out['params_d'] = {k: v.detach().clone() for k, v in sD.items()}
+    if d_override is not None:
+        sD = {k: cvt(d_override[k]).clone().requires_grad_(True) for k in sD}
     del fake_out, real_out, div, d_loss, dgr
     # ---- G phase (:934-989), against the UPDATED discriminator
     style = rng.mixed_list(B, L - 2, LAT); noise = rng.image_noise(B, S_)
@@ -123,5 +132,5 @@ def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hi
             ks = [k for pp, k in keys if pp == p]
             diffgrad({k: s[k] for k in ks}, [grads[(p, k)] for k in ks])
     out['grads'] = grads
-    out['params'] = {(p, k): v.detach() for p, s in [('D', sD)] + groups for k, v in s.items()}
+    out['params'] = {(p, k): v.detach() for p, s in [('D', out['params_d'])] + groups for k, v in s.items()}
     return out

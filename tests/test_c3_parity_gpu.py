@@ -228,14 +228,21 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
     new = {k: v.detach() for k, v in GAN.state_dict().items()}
     gp, pl = step_no % 4 == 0, step_no % 32 == 0
 
+    # the G phase of both oracle runs scores the fakes with the discriminator the product path used (see oracle_step.py:
+    # the first DiffGrad step is sign-like, its result ill-conditioned wherever a gradient is rounding noise)
+    d_used = {k[2:]: v for k, v in new.items() if k.startswith('D.')}
     truth = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, 78, tt=2, dtype=torch.float64), L, HB, ALPHA,
-                              LR, gp, pl)
-    ref32 = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, 78, tt=2), L, HB, ALPHA, LR, gp, pl)
-    rec = dict(d_loss=abs(tr.d_loss - truth['d_loss']), g_loss=abs(tr.g_loss - truth['g_loss']),
-               h_loss=abs(tr.h_loss - truth['h_loss']))
+                              LR, gp, pl, d_override=d_used)
+    ref32 = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, 78, tt=2), L, HB, ALPHA, LR, gp, pl,
+                              d_override=d_used)
+    rel = lambda a, b: abs(a - b) / max(1.0, abs(b))      # the un-normalised logits are >> 1 at this capacity
+    rec = dict(d_loss=rel(tr.d_loss, truth['d_loss']), g_loss=rel(tr.g_loss, truth['g_loss']),
+               h_loss=abs(tr.h_loss - truth['h_loss']), values=dict(d=truth['d_loss'], g=truth['g_loss'], h=truth['h_loss']),
+               g_loss_ref32=rel(ref32['g_loss'], truth['g_loss']))
     assert rec['d_loss'] <= 1e-4 and rec['g_loss'] <= 1e-4 and rec['h_loss'] <= 1e-4, rec
     if gp:
-        rec['gp'] = abs(tr.last_gp_loss - truth['gp']) / max(1.0, abs(truth['gp']))
+        rec['gp'] = rel(tr.last_gp_loss, truth['gp'])
+        rec['values']['gp'] = truth['gp']
         assert rec['gp'] <= 1e-4, rec
 
     # discriminator gradients of the D phase (still in its flat gradient buffer; the G phase does not touch them)
@@ -271,6 +278,9 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
     for (p, k), t in truth['params'].items():
         gr = truth['grads'][(p, k)]
         mask = gr.abs() > 5e-2 * gr.abs().max()
+        if not bool(mask.any()):          # an exactly zero gradient (inactive hinge at this init): no update either way
+            assert torch.equal(new[f'{p}.{k}'], sd0[f'{p}.{k}']), (p, k)
+            continue
         dn = (new[f'{p}.{k}'].double() - sd0[f'{p}.{k}'].double())
         do = (t - sd0[f'{p}.{k}'].double())
         assert float((dn - do).abs()[mask].max()) <= 0.02 * LR, (p, k)

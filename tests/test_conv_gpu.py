@@ -218,3 +218,70 @@ def test_conv_b6_matches_fp64_like_fp32(B, K, N, H, W, gpu_device):
     d6, d32 = relmax(g6.cpu().numpy(), rgx.cpu().numpy()), relmax(g32.cpu().numpy(), rgx.cpu().numpy())
     assert e6 <= 5e-6 and d6 <= 5e-6
     assert e6 <= 5 * e32 + 1e-7 and d6 <= 5 * d32 + 1e-7
+
+
+def test_batched_packing_launch_matches_single_packs_and_leaves_wsq(gpu_device):
+    """hg_conv_pack_weights_multi over a flat buffer of registered weights: both packed operands equal the per-weight
+    hg_conv_pack_weights results bit for bit, and hg_pack_item.wsq holds sum_taps W^2 (the weight factor of the demodulation
+    coefficient, histoGAN/histoGAN.py:427-429) for every weight -- odd channel counts, 1x1 and 3x3."""
+    from histogan_amd import conv as C
+    from histogan_amd.optim import FlatParams
+    torch.manual_seed(9)
+    ws = [torch.nn.Parameter(torch.randn(s, device=gpu_device)) for s in ((40, 24, 3, 3), (3, 70, 1, 1), (130, 33, 3, 3))]
+    flat = FlatParams(ws, with_grad=False)
+    C.enable_pack_cache(ws)
+    try:
+        for w in ws:
+            wq = C.cached(w, 'wsq', lambda t: (_ for _ in ()).throw(AssertionError('wsq must come from the packing launch')))
+            assert torch.allclose(wq, w.detach().pow(2).sum(dim=(2, 3)), rtol=2e-6, atol=1e-7)
+            for mode in (C.PACK_FWD, C.PACK_DGRAD):
+                assert torch.equal(C.pack_weights(w, mode), C._pack_weights(w.detach(), mode))
+        with torch.no_grad():
+            flat.data.mul_(2.0)
+        C.weights_changed(flat.data)
+        wq = C.cached(ws[2], 'wsq', lambda t: None)
+        assert torch.allclose(wq, ws[2].detach().pow(2).sum(dim=(2, 3)), rtol=2e-6, atol=1e-7)
+    finally:
+        C.enable_pack_cache(None)
+
+
+@pytest.mark.parametrize('B,K,N,H,k,stride', [(2, 3, 16, 64, 1, 1), (4, 16, 32, 32, 1, 1), (8, 520, 300, 4, 1, 1),
+                                              (64, 1024, 2048, 2, 1, 1), (3, 24, 40, 16, 3, 1), (2, 16, 16, 32, 3, 2)])
+def test_conv2d_add_equals_conv_then_add(B, K, N, H, k, stride, gpu_device):
+    """hg_conv2d_fwd_add (the residual sum of DiscriminatorBlock in the conv_res epilogue, incl. the K-split launches of the
+    small maps): bit-identical to conv2d(...) + addend, same gradients (the addend's is the incoming one), and the second
+    order works (gradient penalty)."""
+    from histogan_amd.conv import conv2d, conv2d_add
+    torch.manual_seed(B + K + N)
+    x = torch.randn(B, K, H, H, device=gpu_device, requires_grad=True)
+    w = (torch.randn(N, K, k, k, device=gpu_device) / (K * k * k) ** 0.5).requires_grad_(True)
+    b = torch.randn(N, device=gpu_device, requires_grad=True)
+    Ho = (H - 1) // stride + 1
+    ad = torch.randn(B, N, Ho, Ho, device=gpu_device, requires_grad=True)
+    ref = conv2d(x, w, b, stride) + ad
+    out = conv2d_add(x, w, b, ad, stride)
+    assert torch.equal(out, ref)
+    go = torch.randn_like(out)
+    for a, r in zip(torch.autograd.grad(out, (x, w, b, ad), go), torch.autograd.grad(ref, (x, w, b, ad), go)):
+        assert torch.equal(a, r)
+    # second order: d/dw of || d out / d x ||^2
+    def pen(fn):
+        o = fn().pow(2).sum()
+        gx, = torch.autograd.grad(o, x, create_graph=True)
+        return torch.autograd.grad(gx.pow(2).sum(), (w, ad))
+    for a, r in zip(pen(lambda: conv2d_add(x, w, b, ad, stride)), pen(lambda: conv2d(x, w, b, stride) + ad)):
+        assert relmax(a.cpu().numpy(), r.cpu().numpy()) <= 1e-6
+
+
+@pytest.mark.parametrize('shape', [(3, 5, 4, 4), (2, 16, 64, 64), (7, 3, 5, 9), (1, 1, 1, 1), (4, 130, 8, 8)])
+def test_lrelu_bwd_channel_sum_matches_aten(shape, gpu_device):
+    from histogan_amd.conv import lrelu_bwd_channel_sum
+    torch.manual_seed(6)
+    g, out = torch.randn(*shape, device=gpu_device), torch.randn(*shape, device=gpu_device)
+    out[0, 0, 0, 0] = 0.0                                                 # the boundary: slope side (result > 0 is false)
+    ref = torch.ops.aten.leaky_relu_backward(g, out, 0.2, True)
+    gm, cs = lrelu_bwd_channel_sum(g, out, 0.2)
+    assert torch.equal(gm, ref)
+    assert relmax(cs.cpu().numpy(), ref.double().sum(dim=(0, 2, 3)).cpu().numpy()) <= 1e-6
+    gm2, none = lrelu_bwd_channel_sum(g, out, 0.2, want_sum=False)
+    assert none is None and torch.equal(gm2, ref)
