@@ -21,6 +21,7 @@
 //
 // Pixel tiles are NI images x TH rows x TW columns (all powers of two, chosen on the host per layer:
 // 32-wide rows for big maps, several whole images per tile for 4x4 / 8x8 maps).
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include "hg_common.h"
@@ -77,6 +78,11 @@ struct ConvArgs {
   int ntx, wrow0, wrow_dy, wrow_dx;  // packed-weight row of tap t = wrow0 + (t / ntx)*wrow_dy + (t % ntx)*wrow_dx
   int ksplit;      // > 1: blockIdx.z handles a K range and writes raw partial sums to slab[z] (out layout)
   float *slab;
+  // In-kernel combination of the K-split slabs (no k_splitk_reduce launch): flags[tile][z] = tag once block z of a tile
+  // has written its slab; the block that then finds all ksplit flags of its tile set sums the slabs in z order, applies the
+  // epilogue and clears the flags.  `tag` is unique per launch (never 0), so the flag words need no initialisation.
+  unsigned long long *flags;
+  unsigned long long tag;
   // fused generator epilogue (hg_modconv2d_fwd): v = acc*oscale + bias[n] + noise_w[n]*noise_img[b][y][x]; lrelu
   const float *noise_w, *noise_img;
   int noise_S;     // noise_img is (B, noise_S, noise_S)
@@ -364,7 +370,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, con
   // ---- epilogue: D[i = channel][j = pixel]; 32x32: row(i) = (r&3) + 8*(r>>2) + 4*(lane>>5), col(j) = lane&31;
   //      16x16: row = 4*(lane>>4) + r, col = lane&15
   const int HWo = a.Ho * a.Wo;
-  const bool fin = a.ksplit == 1;   // split-K partials get their epilogue in k_splitk_reduce
+  // fin: the finished sums (bias / scales / noise / activation applied, written to `out`); else raw partial sums to slab[z]
+  auto epilogue = [&](const bool fin) __attribute__((always_inline)) {
   if constexpr (!FE) {
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
@@ -431,6 +438,55 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, con
         }
       }
     }
+  }
+  };
+  if (a.ksplit == 1) {
+    epilogue(true);
+    return;
+  }
+  epilogue(false);
+  if (a.flags == nullptr) return;    // the host sums the slabs with k_splitk_reduce
+
+  // ---- last-arriving block of this tile: combine the slabs ("K split without a second launch")
+  __threadfence();                   // this thread's slab stores are visible device-wide ...
+  __syncthreads();                   // ... for every thread of the block (the operand buffers are dead from here on)
+  int *s_last = reinterpret_cast<int *>(smem);
+  if (tid == 0) {
+    unsigned long long *f = a.flags + ((size_t)bidy * (g.tiles_x * g.tiles_y * g.groups) + bidx) * a.ksplit;
+    __hip_atomic_store(&f[bidz], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);     // flag store before flag loads: of two blocks finishing together, one sees both
+    int cnt = 0;
+    for (int z = 0; z < a.ksplit; ++z) cnt += __hip_atomic_load(&f[z], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.tag;
+    *s_last = cnt == a.ksplit;
+  }
+  __syncthreads();
+  if (!*s_last) return;
+  __threadfence();                   // acquire: the other blocks' slabs, not stale cache lines
+  {
+    const size_t total = (size_t)a.B * N * HWo;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+      const int p = (wp * TP + j) * MT + lm;
+      const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
+      const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
+      if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
+      const float *sp = a.slab + ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int r = 0; r < M::NR; ++r) {
+          const int ch = n0 + (wc * TC + i) * MT + M::row(r, lk);
+          float v = 0.f;
+          if (ch < N)
+            for (int z = 0; z < a.ksplit; ++z) v += sp[(size_t)z * total + (size_t)ch * HWo];   // fixed order: deterministic
+          acc[i][j][r] = v;
+        }
+    }
+  }
+  epilogue(true);
+  if (tid == 0) {                    // leave the flags clear: a replayed hipGraph launches this kernel with the same tag
+    unsigned long long *f = a.flags + ((size_t)bidy * (g.tiles_x * g.tiles_y * g.groups) + bidx) * a.ksplit;
+    for (int z = 0; z < a.ksplit; ++z) __hip_atomic_store(&f[z], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -735,7 +791,34 @@ __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a
     }
   }
 
-  if (a.gw != nullptr) {  // WS == 1 and one split: this block's tile IS the result
+  // The WS waves of a tile each hold a partial sum over their share of the pixels: combine them in LDS (fixed order
+  // ws = 0, 1, ..) so that the block leaves ONE slab -- half / a quarter of the slab traffic of the pixel-split tiles,
+  // written and read back by k_wgrad_reduce (37.7 MB -> 18.9 / 9.4 MB per launch on the 256^2 / 128^2 layers).
+  if constexpr (WS > 1) {
+    constexpr int NTW = WN * WK * TS;                  // wave tiles of the block (per pixel split)
+    constexpr int WSZ = TPW * M::NR * 64;              // floats one wave holds
+    const int wtile = wn + WN * (wk + WK * wt);
+    __syncthreads();                                   // operand buffers are dead
+    if (ws > 0) {
+      float *R = smem + ((size_t)(ws - 1) * NTW + wtile) * WSZ + lane;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < M::NR; ++r) R[(t * M::NR + r) * 64] = acc[t][r];
+    }
+    __syncthreads();
+    if (ws > 0) return;
+#pragma unroll
+    for (int w2 = 1; w2 < WS; ++w2) {
+      const float *R = smem + ((size_t)(w2 - 1) * NTW + wtile) * WSZ + lane;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int r = 0; r < M::NR; ++r) acc[t][r] += R[(t * M::NR + r) * 64];
+    }
+  }
+
+  if (a.gw != nullptr) {  // one split: this block's tile IS the result
     if constexpr (WS == 1 && MT == 32 && TAPS == 9) {
       if ((K & 3) == 0) {
         // The (n, k, tap) layout makes a wave's 32n x 32k x 9 tile 32 contiguous 1152-byte runs: transpose it through
@@ -771,8 +854,8 @@ __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a
       }
     return;
   }
-  // slab[split*WS + ws][t][n][k]: D[i = n][j = k]
-  float *sb = a.slab + ((size_t)blockIdx.y * WS + ws) * TAPS * a.Np32 * a.Kp32;
+  // slab[split][t][n][k]: D[i = n][j = k]
+  float *sb = a.slab + (size_t)blockIdx.y * TAPS * a.Np32 * a.Kp32;
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
@@ -783,32 +866,38 @@ __global__ __launch_bounds__(WN *WK *WS *TS * 64) void k_wgrad(const WgradArgs a
     }
 }
 
-// row pitch (floats) of the LDS transpose of a wave's 32 x (32 k x 9 taps) tile: multiple of 4 (16-byte rows)
-// gw[n][k][t] = sum_s slab[s][t][n][k].  One block per (n, tap, 32 k's): 32 lanes along k x 8 groups of
-// splits, fixed-order combine through LDS (deterministic).
+// gw[n][k][t] = sum_s slab[s][t][n][k].  One block per (n, tap, 32 k's): 8 lanes x 16-byte loads along k, 32 groups of
+// splits with four independent loads in flight each (the slabs of the 256^2 / 128^2 layers are 10-20 MB per launch: the
+// kernel is a bandwidth problem -- 4-byte loads in 8 groups ran at 1 TB/s), fixed-order combine through LDS (deterministic).
 template <int TAPS>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ slab, float *__restrict__ gw, int N, int K,
                                                       int Np32, int Kp32, int splits) {
-  __shared__ float part[8][32];
-  const int kx = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int k = blockIdx.x * 32 + kx, t = blockIdx.y, n = blockIdx.z;
+  __shared__ float part[32][33];
+  const int k4 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const int kb = blockIdx.x * 32 + k4 * 4, t = blockIdx.y, n = blockIdx.z;
   const size_t sstride = (size_t)TAPS * Np32 * Kp32;
-  const float *p = slab + ((size_t)t * Np32 + n) * Kp32 + (k < Kp32 ? k : 0);   // Kp32: multiple of the tile (16 / 32)
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int sp = grp;
-  for (; sp + 24 < splits; sp += 32) {
-    s0 += p[(size_t)sp * sstride];
-    s1 += p[(size_t)(sp + 8) * sstride];
-    s2 += p[(size_t)(sp + 16) * sstride];
-    s3 += p[(size_t)(sp + 24) * sstride];
+  const bool in = kb < Kp32;                                   // Kp32 is a multiple of the tile (16 / 32), kb of 4
+  const float *p = slab + ((size_t)t * Np32 + n) * Kp32 + (in ? kb : 0);
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  if (in) {
+    int sp = grp;
+    for (; sp + 96 < splits; sp += 128) {
+      s0 += *reinterpret_cast<const f32x4 *>(p + (size_t)sp * sstride);
+      s1 += *reinterpret_cast<const f32x4 *>(p + (size_t)(sp + 32) * sstride);
+      s2 += *reinterpret_cast<const f32x4 *>(p + (size_t)(sp + 64) * sstride);
+      s3 += *reinterpret_cast<const f32x4 *>(p + (size_t)(sp + 96) * sstride);
+    }
+    for (; sp < splits; sp += 32) s0 += *reinterpret_cast<const f32x4 *>(p + (size_t)sp * sstride);
   }
-  for (; sp < splits; sp += 8) s0 += p[(size_t)sp * sstride];
-  part[grp][kx] = (s0 + s1) + (s2 + s3);
+  const f32x4 v4 = (s0 + s1) + (s2 + s3);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) part[grp][k4 * 4 + c] = v4[c];
   __syncthreads();
-  if (grp == 0 && k < K) {
+  const int kx = threadIdx.x, k = blockIdx.x * 32 + kx;
+  if (kx < 32 && k < K) {
     float v = 0.f;
 #pragma unroll
-    for (int g2 = 0; g2 < 8; ++g2) v += part[g2][kx];
+    for (int g2 = 0; g2 < 32; ++g2) v += part[g2][kx];
     gw[((size_t)n * K + k) * TAPS + t] = v;
   }
 }
@@ -930,17 +1019,31 @@ inline int ceil_log2(int v) {
 }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// log2 of the pixel tile (width, height, images) for MB compute-grid pixels per block over an Hc x Wc grid
+inline void tile_shape(int MB, int Hc, int Wc, int min_t, int &lTW, int &lTH, int &lNI) {
+  lTW = ceil_log2(Wc < min_t ? min_t : Wc);
+  if (lTW > 5) lTW = 5;
+  const int lMB = ceil_log2(MB);
+  if (lTW > lMB - 1) lTW = lMB - 1;
+  lTH = ceil_log2(Hc < min_t ? min_t : Hc);
+  if (lTH > lMB - lTW) lTH = lMB - lTW;
+  lNI = lMB - lTW - lTH;
+}
+// pixel tiles (grid x extent) of a launch with MB pixels per block
+inline long long pixel_tiles(int MB, int B, int Hc, int Wc, int min_t) {
+  int lTW, lTH, lNI;
+  tile_shape(MB, Hc, Wc, min_t, lTW, lTH, lNI);
+  const int TW = 1 << lTW, TH = 1 << lTH, NI = 1 << lNI;
+  return (long long)((Wc + TW - 1) / TW) * ((Hc + TH - 1) / TH) * ((B + NI - 1) / NI);
+}
+
 // pixel-tile geometry for MB compute-grid pixels per block over an Hc x Wc grid; taps span [lo, hi] in y and x
 Geom make_geom(int MB, int B, int Hc, int Wc, int IS, int lo_y, int hi_y, int lo_x, int hi_x, bool odd_chs,
                int min_t = 4) {
   Geom g;
-  int lTW = ceil_log2(Wc < min_t ? min_t : Wc);
-  if (lTW > 5) lTW = 5;
-  const int lMB = ceil_log2(MB);
-  if (lTW > lMB - 1) lTW = lMB - 1;
-  int lTH = ceil_log2(Hc < min_t ? min_t : Hc);
-  if (lTH > lMB - lTW) lTH = lMB - lTW;
-  g.lTW = lTW; g.lTH = lTH; g.lNI = lMB - lTW - lTH;
+  int lTW, lTH, lNI;
+  tile_shape(MB, Hc, Wc, min_t, lTW, lTH, lNI);
+  g.lTW = lTW; g.lTH = lTH; g.lNI = lNI;
   const int TW = 1 << lTW, TH = 1 << lTH, NI = 1 << g.lNI;
   g.TWp = (TW - 1) * IS + 1 + (hi_x - lo_x);
   g.IMS = ((TH - 1) * IS + 1 + (hi_y - lo_y)) * g.TWp;
@@ -1084,6 +1187,12 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
 
 inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st);
 
+// a launch tag: unique per call within the process, never 0
+inline unsigned long long next_conv_tag() {
+  static std::atomic<unsigned long long> ctr{0x9E3779B97F4A7C15ull ^ ((unsigned long long)(uintptr_t)&ctr << 17)};
+  return ctr.fetch_add(2, std::memory_order_relaxed) | 1ull;
+}
+
 // output blocks of a plan over B x Hc x Wc compute pixels (before the K split)
 inline long long plan_blocks(const ConvPlan &p, int B, int N, int Hc, int Wc) {
   const long long px = (long long)B * Hc * Wc;
@@ -1149,11 +1258,22 @@ inline int fit_blocks_per_cu(const void *kern, int threads, long long nwg, size_
   return 0;
 }
 
+// ws_bytes: size of the scratch behind a.slab (0: unknown -> no in-kernel combination)
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM = false, int MT = 32>
-int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t st) {
+int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t st, size_t ws_bytes = 0) {
   constexpr int NB = WC * TC * MT, NT = WC * WP * 64;
   size_t lds = prep_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT>(a, tp, ksplit);
   if (!lds) return HG_EUNSUPPORTED;
+  a.flags = nullptr; a.tag = 0;
+  if (ksplit > 1 && reduce) {
+    static const bool inkernel = !(getenv("HG_CONV_SPLITK_INKERNEL") && atoi(getenv("HG_CONV_SPLITK_INKERNEL")) == 0);
+    const size_t slab_b = ((size_t)ksplit * a.B * a.N * a.Ho * a.Wo * sizeof(float) + 255) / 256 * 256;
+    const size_t flag_b = (size_t)a.g.tiles_x * a.g.tiles_y * a.g.groups * ((a.N + NB - 1) / NB) * ksplit * sizeof(unsigned long long);
+    if (inkernel && ws_bytes >= slab_b + flag_b) {
+      a.flags = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.slab) + slab_b);
+      a.tag = next_conv_tag();
+    }
+  }
   const bool fe = a.iscale || a.oscale || a.noise_img || a.slope > 0.f;
   auto kern = fe ? k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, true> : k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, false>;
   static int state[2][2] = {{0, 0}, {0, 0}};
@@ -1164,7 +1284,7 @@ int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t
   const dim3 grid((unsigned)(a.g.tiles_x * a.g.tiles_y * a.g.groups), (unsigned)((a.N + NB - 1) / NB), (unsigned)ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);
   HG_LAUNCH_CHECK();
-  if (ksplit > 1 && reduce) return launch_splitk_reduce(a, ksplit, st);
+  if (ksplit > 1 && reduce && a.flags == nullptr) return launch_splitk_reduce(a, ksplit, st);
   return HG_OK;
 }
 
@@ -1178,6 +1298,7 @@ int launch_conv_parity4(const ConvArgs (&base)[4], const Taps (&tp)[4], int kspl
   int tiles_max = 0;
   for (int c = 0; c < 4; ++c) {
     a4.c[c] = base[c];
+    a4.c[c].flags = nullptr; a4.c[c].tag = 0;    // the caller sums the slabs of the four classes
     a4.tiles[c] = 0;
     if (base[c].Hc <= 0 || base[c].Wc <= 0) continue;   // empty class (1-pixel-wide image)
     size_t l = c == 0 ? prep_conv<WC, WP, TC, TP, 1, KC, 1, SM, MT>(a4.c[c], tp[c], ksplit)
@@ -1201,9 +1322,22 @@ int launch_conv_parity4(const ConvArgs (&base)[4], const Taps (&tp)[4], int kspl
   return HG_OK;
 }
 
-inline size_t conv_ws_bytes(const ConvPlan &p, int B, int N, int Ho, int Wo) {
-  return p.ksplit > 1 ? (size_t)p.ksplit * B * N * Ho * Wo * sizeof(float) : 0;
+// K-split scratch: ksplit slabs in `out` layout, then (256-byte aligned) one 64-bit flag per (output tile, split) for the
+// in-kernel combination.  Hc x Wc: the compute grid of the launch (== Ho x Wo for stride-1 / forward launches).
+inline size_t conv_slab_bytes(const ConvPlan &p, int B, int N, int Ho, int Wo) {
+  return p.ksplit > 1 ? ((size_t)p.ksplit * B * N * Ho * Wo * sizeof(float) + 255) / 256 * 256 : 0;
 }
+inline size_t conv_flag_bytes(const ConvPlan &p, int B, int N, int Hc, int Wc) {
+  if (p.ksplit <= 1) return 0;
+  const int nbt = p.tile == TILE_16x256 ? 16 : p.tile == TILE_32x256 ? 32 : (p.tile == TILE_64x256 || p.tile == TILE_64x64) ? 64 : 128;
+  const int mbt = (p.tile == TILE_128x128 || p.tile == TILE_128x128_SM) ? 128 : p.tile == TILE_64x64 ? 64 : 256;
+  const int min_t = (p.tile == TILE_128x128_SM || p.tile == TILE_64x64) ? 2 : 4;
+  return (size_t)pixel_tiles(mbt, B, Hc, Wc, min_t) * ((N + nbt - 1) / nbt) * p.ksplit * sizeof(unsigned long long);
+}
+inline size_t conv_ws_bytes(const ConvPlan &p, int B, int N, int Ho, int Wo) {
+  return conv_slab_bytes(p, B, N, Ho, Wo) + conv_flag_bytes(p, B, N, Ho, Wo);
+}
+
 
 inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st) {
   const long long total = (long long)a.B * a.N * a.Ho * a.Wo;
@@ -1222,7 +1356,7 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
   a.slab = (float *)ws;
   if (force_ksplit > 0) return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, true>(a, tp, force_ksplit, false, st);
   ConvPlan p = plan_conv(a.B, a.K, a.N, a.Hc, a.Wc, IS, a.os, ws != nullptr, true, TAPS);
-  if (conv_ws_bytes(p, a.B, a.N, a.Ho, a.Wo) > ws_bytes) p.ksplit = 1;   // too little scratch: no K split
+  if (conv_slab_bytes(p, a.B, a.N, a.Ho, a.Wo) > ws_bytes) p.ksplit = 1;   // too little scratch: no K split
   // 3x3 stride-1 launches also exist with 2-channel K chunks: 16 fewer staging registers = one more block per CU (4
   // instead of 3).  Taken when that makes the launch whole rounds (1024 / 2048 blocks: 134 -> 139 TFLOP/s) and for the
   // 32-channel tile (+2..5 %); deep-K layers lose 3 % to the doubled barrier count and keep the 4-channel chunks.
@@ -1241,11 +1375,11 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
       return launch_conv<1, 4, 1, 4, TAPS, 4, IS, false, 16>(a, tp, 1, true, st);
     case TILE_32x256: return launch_conv<1, 4, 1, 2, TAPS, KC, IS>(a, tp, 1, true, st);
     case TILE_64x256: return launch_conv<1, 4, 2, 2, TAPS, KC, IS>(a, tp, 1, true, st);
-    case TILE_128x128: return launch_conv<2, 2, 2, 2, TAPS, KC, IS>(a, tp, p.ksplit, true, st);
+    case TILE_128x128: return launch_conv<2, 2, 2, 2, TAPS, KC, IS>(a, tp, p.ksplit, true, st, ws_bytes);
     case TILE_128x128_SM:
-      if constexpr (IS == 1) return launch_conv<2, 2, 2, 2, TAPS, KC, IS, true>(a, tp, p.ksplit, true, st);
+      if constexpr (IS == 1) return launch_conv<2, 2, 2, 2, TAPS, KC, IS, true>(a, tp, p.ksplit, true, st, ws_bytes);
       else return HG_EUNSUPPORTED;
-    default: return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, true>(a, tp, p.ksplit, true, st);
+    default: return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, true>(a, tp, p.ksplit, true, st, ws_bytes);
   }
 }
 
@@ -1306,7 +1440,7 @@ WgradPlan make_wgrad_plan(int B, int K, int N, int Hi, int Wi, int ksize, int st
   p.splits = s;
   p.Kp32 = p.ktiles * p.WK * p.MT;
   p.Np32 = p.ntiles * p.WN * p.MT;
-  p.slab_bytes = (size_t)s * p.WS * ksize * ksize * p.Kp32 * p.Np32 * sizeof(float);
+  p.slab_bytes = (size_t)s * ksize * ksize * p.Kp32 * p.Np32 * sizeof(float);   // one slab per block (WS waves combined in LDS)
   return p;
 }
 
@@ -1318,6 +1452,10 @@ int launch_wgrad_k(const WgradArgs &a, const WgradPlan &p, hipStream_t st) {
   if ((WS == 1 || (TS > 1 && HG_WGRAD_TS_DBUF)) && 2 * lds <= 160 * 1024) lds *= 2;   // double buffered (NBUF in k_wgrad)
   if (a.gw != nullptr && WS == 1 && MT == 32 && TAPS == 9) {   // room for the store transpose of the single-slab case
     const size_t need = (size_t)WN * WK * 32 * WG_TP * sizeof(float);
+    if (need > lds) lds = need;
+  }
+  if (WS > 1) {   // the in-block combination of the WS partial tiles
+    const size_t need = (size_t)(WS - 1) * WN * WK * TS * (TAPS / TS) * (MT == 32 ? 16 : 4) * 64 * sizeof(float);
     if (need > lds) lds = need;
   }
   const bool sc = a.iscale != nullptr || a.gscale != nullptr;
@@ -1369,7 +1507,7 @@ template <int TAPS, int IS>
 int launch_wgrad(WgradArgs a, const WgradPlan &p, float *gw, hipStream_t st) {
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y;
   a.nchunks = p.nchunks; a.splits = p.splits; a.ktiles = p.ktiles; a.Kp32 = p.Kp32; a.Np32 = p.Np32;
-  a.gw = (p.splits * p.WS == 1) ? gw : nullptr;
+  a.gw = (p.splits == 1) ? gw : nullptr;
   int rc;
   switch (p.lTW) {
     case 1: rc = launch_wgrad_g<TAPS, 1, IS>(a, p, st); break;
@@ -1380,7 +1518,7 @@ int launch_wgrad(WgradArgs a, const WgradPlan &p, float *gw, hipStream_t st) {
   }
   if (rc || a.gw) return rc;
   hipLaunchKernelGGL(k_wgrad_reduce<TAPS>, dim3((unsigned)((a.K + 31) / 32), (unsigned)TAPS, (unsigned)a.N), dim3(256), 0, st,
-                     a.slab, gw, a.N, a.K, p.Np32, p.Kp32, p.splits * p.WS);
+                     a.slab, gw, a.N, a.K, p.Np32, p.Kp32, p.splits);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }

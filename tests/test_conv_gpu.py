@@ -285,3 +285,27 @@ def test_lrelu_bwd_channel_sum_matches_aten(shape, gpu_device):
     assert relmax(cs.cpu().numpy(), ref.double().sum(dim=(0, 2, 3)).cpu().numpy()) <= 1e-6
     gm2, none = lrelu_bwd_channel_sum(g, out, 0.2, want_sum=False)
     assert none is None and torch.equal(gm2, ref)
+
+
+@pytest.mark.parametrize('B,K,N,H', [(32, 2048, 1024, 8), (16, 2048, 2048, 4), (64, 1024, 2048, 2), (32, 1024, 512, 16)])
+def test_splitk_launches_combine_in_kernel_deterministically(B, K, N, H, gpu_device):
+    """K-split launches (few pixels, many channels) sum their slabs in the last-arriving block of every output tile
+    (flags in the workspace, no second launch): the plan says K split > 1, results repeat bit for bit (fixed z order,
+    whichever block arrives last) and match fp64; a forward and a data gradient."""
+    import ctypes
+    from histogan_amd._lib import lib
+    from histogan_amd.conv import conv2d_same
+    plan = (ctypes.c_int32 * 5)()
+    assert lib.hg_conv2d_plan(B, K, N, H, H, 3, 1, 0, plan) == 0 and plan[1] > 1
+    torch.manual_seed(K + N + H)
+    x = torch.randn(B, K, H, H, device=gpu_device, requires_grad=True)
+    w = (torch.randn(N, K, 3, 3, device=gpu_device) / (K * 9) ** 0.5).requires_grad_(True)
+    go = torch.randn(B, N, H, H, device=gpu_device)
+    outs = []
+    for _ in range(6):
+        y = conv2d_same(x, w)
+        gx, = torch.autograd.grad(y, x, go)
+        outs.append((y.detach(), gx))
+    assert all(torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) for o in outs[1:])
+    ref = F.conv2d(x.detach().double(), w.detach().double(), padding=1)
+    assert relmax(outs[0][0].cpu().numpy(), ref.cpu().numpy()) <= 5e-6
