@@ -463,27 +463,69 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, con
   if (!*s_last) return;
   __threadfence();                   // acquire: the other blocks' slabs, not stale cache lines
   {
+    // The tile as a flat (channel, pixel) range over all threads -- k_splitk_reduce's arithmetic restricted to this tile,
+    // independent of the MFMA register layout (reloading the slabs into the accumulators and re-running the epilogue cost the
+    // whole kernel its third block per CU in registers).  16-byte loads where rows allow: four pixels of a row per thread,
+    // ksplit x 16 B in flight per element group; fixed z order: deterministic.
     const size_t total = (size_t)a.B * N * HWo;
-#pragma unroll
-    for (int j = 0; j < TP; ++j) {
-      const int p = (wp * TP + j) * MT + lm;
-      const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
-      const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
-      if (b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
-      const float *sp = a.slab + ((size_t)b * N) * HWo + (cy * a.os + a.oy) * a.Wo + cx * a.os + a.ox;
-#pragma unroll
-      for (int i = 0; i < TC; ++i)
-#pragma unroll
-        for (int r = 0; r < M::NR; ++r) {
-          const int ch = n0 + (wc * TC + i) * MT + M::row(r, lk);
-          float v = 0.f;
-          if (ch < N)
-            for (int z = 0; z < a.ksplit; ++z) v += sp[(size_t)z * total + (size_t)ch * HWo];   // fixed order: deterministic
-          acc[i][j][r] = v;
+    constexpr int lMB = MB == 256 ? 8 : (MB == 128 ? 7 : 6);
+    static_assert((1 << lMB) == MB, "pixels per block");
+    auto finish = [&](float v, const int ch, const int b, const int cy, const int cx, const size_t idx) __attribute__((always_inline)) {
+      float add = a.bias ? a.bias[ch] : 0.f;
+      if (a.noise_img) add = fmaf(a.noise_w[ch], a.noise_img[((size_t)b * a.noise_S + cy) * a.noise_S + cx], add);
+      v = a.oscale ? fmaf(v, a.oscale[b * N + ch], add) : v + add;
+      if (a.addend) v += a.addend[idx];
+      if (a.slope > 0.f) v = v > 0.f ? v : a.slope * v;
+      return v;
+    };
+    const bool vec = g.lTW >= 2 && (a.Wo & 3) == 0 && a.os == 1 && (HWo & 3) == 0;
+    if (vec) {
+      for (int e = tid * 4; e < NB * MB; e += NT * 4) {
+        const int cl = e >> lMB, p = e & (MB - 1);
+        const int ch = n0 + cl;
+        const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
+        const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
+        if (ch >= N || b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;     // (Wc == Wo, a multiple of 4: whole groups)
+        const size_t idx = ((size_t)b * N + ch) * HWo + (size_t)cy * a.Wo + cx;
+        // four independent partial sums: four slabs' loads in flight per thread (order fixed by z alone: deterministic)
+        const float *sp = a.slab + idx;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+        int z = 0;
+        for (; z + 3 < a.ksplit; z += 4) {
+          v0 += *reinterpret_cast<const f32x4 *>(sp + (size_t)z * total);
+          v1 += *reinterpret_cast<const f32x4 *>(sp + (size_t)(z + 1) * total);
+          v2 += *reinterpret_cast<const f32x4 *>(sp + (size_t)(z + 2) * total);
+          v3 += *reinterpret_cast<const f32x4 *>(sp + (size_t)(z + 3) * total);
         }
+        for (; z < a.ksplit; ++z) v0 += *reinterpret_cast<const f32x4 *>(sp + (size_t)z * total);
+        const f32x4 v = (v0 + v1) + (v2 + v3);
+        f32x4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = finish(v[q], ch, b, cy, cx + q, idx + q);
+        *reinterpret_cast<f32x4 *>(a.out + idx) = o;
+      }
+    } else {
+      for (int e = tid; e < NB * MB; e += NT) {
+        const int cl = e >> lMB, p = e & (MB - 1);
+        const int ch = n0 + cl;
+        const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
+        const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
+        if (ch >= N || b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
+        const int oyy = cy * a.os + a.oy, oxx = cx * a.os + a.ox;
+        const size_t idx = ((size_t)b * N + ch) * HWo + (size_t)oyy * a.Wo + oxx;
+        const float *sp = a.slab + idx;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int z = 0;
+        for (; z + 3 < a.ksplit; z += 4) {
+          v0 += sp[(size_t)z * total]; v1 += sp[(size_t)(z + 1) * total];
+          v2 += sp[(size_t)(z + 2) * total]; v3 += sp[(size_t)(z + 3) * total];
+        }
+        for (; z < a.ksplit; ++z) v0 += sp[(size_t)z * total];
+        a.out[idx] = finish((v0 + v1) + (v2 + v3), ch, b, oyy, oxx, idx);
+      }
     }
   }
-  epilogue(true);
+  __syncthreads();
   if (tid == 0) {                    // leave the flags clear: a replayed hipGraph launches this kernel with the same tag
     unsigned long long *f = a.flags + ((size_t)bidy * (g.tiles_x * g.tiles_y * g.groups) + bidx) * a.ksplit;
     for (int z = 0; z < a.ksplit; ++z) __hip_atomic_store(&f[z], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -28,6 +28,7 @@
 // v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain (no reduced-precision path on gfx950).
 #include "hg_common.h"
 #include "../../include/hg_hist.h"
+#include <atomic>
 #include <cstdlib>
 
 #define HG_VERSION_NUM 102   // 102: hg_hist_params.struct_size (ABI guard), hg_rgbuv_hist_uses_proj_cache
@@ -210,12 +211,30 @@ __device__ __forceinline__ void lds_wave_sync() {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Projection pre-pass of the dense forward: clamp / resize / three fp64 logarithms per pixel (~370 VALU instructions) at full
+// occupancy in a kernel of its own, 16 (or 32: with the backward's colour record) bytes per pixel out.  Inside k_hist_fwd
+// that work cost matrix-pipe time -- fp32 MFMA and VALU share the issue path on gfx950 (tools/ubench/mfma_valu_overlap.hip):
+// 3.3 non-MFMA VALU instructions per MFMA, a third of them the projection (profiles/r02_hist_pmc_raw.txt).
+// dst[(b*npix + n)*pstride] = (a, b, c, Iy); pstride == 2: dst[.. + 1] = (r, g, b, 0) (hg_hist_params.proj_cache layout).
+__global__ __launch_bounds__(256) void k_hist_project(const DevParams P, const float *__restrict__ x,
+                                                      float4 *__restrict__ dst, const int pstride) {
+  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= P.npix) return;
+  float r, g, bl, a, bb, c, iy;
+  sample_rgb(P, x + (long long)b * P.sb, n, r, g, bl);
+  project(P, r, g, bl, a, bb, c, iy);
+  float4 *d = dst + ((long long)b * P.npix + n) * pstride;
+  d[0] = make_float4(a, bb, c, iy);
+  if (pstride == 2) d[1] = make_float4(r, g, bl, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Forward.  grid = (S splits, nbd*nbd output blocks, B images), 256 threads = 4 independent waves.
 // Each wave owns a contiguous run of `chunk` pixels and accumulates a (3 x BLK x BLK) partial
 // histogram block (BLK = 32*T) in 3*T*T MFMA accumulator tiles; the 4 waves are then summed through
 // LDS in fixed order and written as one slab  slabs[b][s][p][h][h]  (real bin order, flips undone).
 template <int T, int METHOD, bool SYM, bool DIAG, bool GREEN>
-__global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const float *__restrict__ x,
+__global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const float4 *__restrict__ proj, const int pstride,
                                                      float *__restrict__ slabs, double *__restrict__ slab_tot,
                                                      const int chunk) {
   constexpr int BLK = 32 * T;
@@ -228,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
   const int nbd = (P.h + BLK - 1) / BLK;
   const int bi = blockIdx.y / nbd, bj = blockIdx.y - bi * nbd;
   const int b = blockIdx.z, s = blockIdx.x, S = gridDim.x;
-  const float *xb = x + (long long)b * P.sb;
+  const float4 *pb = proj + (long long)b * P.npix * pstride;   // (a, b, c, Iy) per pixel, from k_hist_project
 
   // per-lane bin constants: A side = rows (i) of this block, B side = columns (j)
   BinC cA[T], cAm[T], cB[T], cBm[T];
@@ -298,20 +317,13 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
     }
   };
 
-  float r_ = 0.f, g_ = 0.f, b_ = 0.f;
-  if (start + lane < end) sample_rgb(P, xb, (int)start + lane, r_, g_, b_);
+  float4 q_ = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (start + lane < end) q_ = pb[((long long)start + lane) * pstride];
   for (int base = (int)start; base < end; base += 64) {
-    float a, bb, c, iy;
-    project(P, r_, g_, b_, a, bb, c, iy);
     const bool valid = base + lane < end;
-    stage[wave * 64 + lane] = valid ? make_float4(a, bb, c, iy) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (P.cache && valid && blockIdx.y == 0) {          // one writer per pixel (the bin-block replicas skip it)
-      float4 *cp = P.cache + ((long long)b * P.npix + base + lane) * 2;
-      cp[0] = make_float4(a, bb, c, iy);
-      cp[1] = make_float4(r_, g_, b_, 0.f);
-    }
+    stage[wave * 64 + lane] = valid ? q_ : make_float4(0.f, 0.f, 0.f, 0.f);
     // prefetch the next 64 pixels while this batch is in the MFMA loop
-    if (base + 64 + lane < end) sample_rgb(P, xb, base + 64 + lane, r_, g_, b_);
+    if (base + 64 + lane < end) q_ = pb[((long long)base + 64 + lane) * pstride];
     lds_wave_sync();
     const int steps = (min(64, end - base) + 1) >> 1;
     // Software-pipelined K loop: the operands of step m+1 (VALU: 3..6 kernel vectors) are generated next to the
@@ -1332,7 +1344,8 @@ template <bool DIRECT, bool SYM>
 __global__ __launch_bounds__(1024) void k_thr_fwd_lean(const DevParams P, const float *__restrict__ x,
                                                        float *__restrict__ slabs, double *__restrict__ slab_tot,
                                                        float *__restrict__ hist, float *__restrict__ sum_out,
-                                                       int per_block, const bool exact_only) {
+                                                       int per_block, const bool exact_only,
+                                                       unsigned long long *__restrict__ flags, const unsigned long long tag) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned long long sm_tot[16];
   unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem);   // [3][h][h]
@@ -1421,6 +1434,56 @@ __global__ __launch_bounds__(1024) void k_thr_fwd_lean(const DevParams P, const 
   }
   tot = block_sum_u64<1024>(tot, sm_tot);
   if (threadIdx.x == 0) slab_tot[b * S + s] = (double)tot * (1.0 / kThrScale);
+  if (flags == nullptr) return;      // k_hist_finish sums the slabs
+
+  // ---- ONE launch per direction at batch 32 too: the workgroup that finds all S slabs of its image written sums them (slab
+  // order, exactly k_hist_finish's arithmetic), normalises and writes the histogram.  flags[b][s] = tag (unique per launch,
+  // never 0: no initialisation needed) marks slab (b, s) as written; of two workgroups finishing together at least one
+  // sees both flags (release store, seq_cst fence, acquire loads) -- if both do, both write the same values.  Nobody waits.
+  __threadfence();
+  __syncthreads();
+  int *s_last = reinterpret_cast<int *>(sm_tot);
+  if (threadIdx.x == 0) {
+    unsigned long long *f = flags + (size_t)b * S;
+    __hip_atomic_store(&f[s], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    int cnt = 0;
+    for (int z = 0; z < S; ++z) cnt += __hip_atomic_load(&f[z], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == tag;
+    *s_last = cnt == S;
+  }
+  __syncthreads();
+  if (!*s_last) return;
+  __threadfence();
+  {
+    const double *tp = slab_tot + (size_t)b * S;
+    double tsum = 0.0;
+    for (int z = 0; z < S; ++z) tsum += tp[z];
+    const float den = (float)tsum + kEps;
+    if (threadIdx.x == 0) sum_out[b] = den;
+    const float *src = slabs + (size_t)b * S * 3 * hh;
+    float *dst = hist + (size_t)b * 3 * hh;
+    const int nel = 3 * hh, nq2 = nel >> 2;
+    if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0 && (nel & 3) == 0) {
+      for (int e4 = threadIdx.x; e4 < nq2; e4 += 1024) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < S; ++z) {
+          const float4 t = reinterpret_cast<const float4 *>(src + (size_t)z * nel)[e4];
+          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        reinterpret_cast<float4 *>(dst)[e4] = make_float4(v.x / den, v.y / den, v.z / den, v.w / den);
+      }
+    } else {
+      for (int e = threadIdx.x; e < nel; e += 1024) {
+        float v = 0.f;
+        for (int z = 0; z < S; ++z) v += src[(size_t)z * nel + e];
+        dst[e] = v / den;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {            // flags clear again: a replayed hipGraph re-launches with the same tag
+    unsigned long long *f = flags + (size_t)b * S;
+    for (int z = 0; z < S; ++z) __hip_atomic_store(&f[z], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // One-launch backward: <G, out> is rebuilt per workgroup (2 x 48 KB from L2, as k_hist_bwd does) instead of a
@@ -1765,6 +1828,8 @@ struct Plan {
   int nparts;                // reduce blocks per image
   int S_bwd, rounds;         // backward: WGs per image, 32-pixel rounds per wave
   size_t slab_bytes, part_bytes, gh_bytes, gxs_bytes;
+  size_t flag_bytes;         // forward: one 64-bit arrival flag per (image, split) behind the slabs (lean scatter path)
+  size_t proj_bytes;         // forward, dense path: (a, b, c, Iy) per pixel from the projection pre-pass (16 B / pixel)
   int planes_rt;             // > 0: backward on k_hist_bwd_planes<planes_rt> (see bwd_planes_rt)
 };
 
@@ -1862,7 +1927,9 @@ Plan make_plan(const hg_hist_params *p) {
   pl.chunk = (int)chunk;
   const long long n_per_img = (long long)P * p->h * p->h;
   pl.nparts = (int)((n_per_img + 1023) / 1024);
-  pl.slab_bytes = (size_t)p->B * S * n_per_img * sizeof(float);
+  pl.slab_bytes = ((size_t)p->B * S * n_per_img * sizeof(float) + 255) / 256 * 256;
+  pl.flag_bytes = ((size_t)p->B * S * sizeof(unsigned long long) + 255) / 256 * 256;
+  pl.proj_bytes = sparse_path(p) ? 0 : ((size_t)p->B * npix * sizeof(float4) + 255) / 256 * 256;
   pl.part_bytes = ((size_t)p->B * pl.nparts * sizeof(float) + 255) / 256 * 256;
   // slab_tot[B][S (x bin blocks)] doubles for k_hist_finish
   pl.part_bytes = ((size_t)p->B * S * pl.nbd * pl.nbd * sizeof(double) + 255) / 256 * 256;
@@ -1916,32 +1983,32 @@ DevParams make_dev(const hg_hist_params *p) {
 }
 
 template <int T, int METHOD, bool GREEN>
-int launch_fwd_tmg(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, double *slab_tot,
+int launch_fwd_tmg(const DevParams &d, const Plan &pl, bool sym, const float4 *x, int pstride, float *slabs, double *slab_tot,
                    hipStream_t st) {
   const dim3 grid(pl.S_fwd, pl.nbd * pl.nbd, d.B), block(256);
   const size_t lds = 4 * 64 * 16 + (size_t)3 * pl.BLK * pl.BLK * sizeof(float);
   const bool diag = pl.nbd == 1;
-  if (sym && diag) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, true, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
-  else if (sym) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, false, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
-  else hipLaunchKernelGGL((k_hist_fwd<T, METHOD, false, false, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
+  if (sym && diag) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, true, GREEN>), grid, block, lds, st, d, x, pstride, slabs, slab_tot, pl.chunk);
+  else if (sym) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, false, GREEN>), grid, block, lds, st, d, x, pstride, slabs, slab_tot, pl.chunk);
+  else hipLaunchKernelGGL((k_hist_fwd<T, METHOD, false, false, GREEN>), grid, block, lds, st, d, x, pstride, slabs, slab_tot, pl.chunk);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
 
 template <int T, int METHOD>
-int launch_fwd_tm(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, double *slab_tot,
+int launch_fwd_tm(const DevParams &d, const Plan &pl, bool sym, const float4 *x, int pstride, float *slabs, double *slab_tot,
                   hipStream_t st) {
-  return d.green ? launch_fwd_tmg<T, METHOD, true>(d, pl, sym, x, slabs, slab_tot, st)
-                 : launch_fwd_tmg<T, METHOD, false>(d, pl, sym, x, slabs, slab_tot, st);
+  return d.green ? launch_fwd_tmg<T, METHOD, true>(d, pl, sym, x, pstride, slabs, slab_tot, st)
+                 : launch_fwd_tmg<T, METHOD, false>(d, pl, sym, x, pstride, slabs, slab_tot, st);
 }
 
 template <int T>
-int launch_fwd_t(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, double *slab_tot,
+int launch_fwd_t(const DevParams &d, const Plan &pl, bool sym, const float4 *x, int pstride, float *slabs, double *slab_tot,
                  hipStream_t st) {
   switch (d.method) {
-    case HG_METHOD_THRESHOLDING: return launch_fwd_tm<T, HG_METHOD_THRESHOLDING>(d, pl, sym, x, slabs, slab_tot, st);
-    case HG_METHOD_RBF: return launch_fwd_tm<T, HG_METHOD_RBF>(d, pl, sym, x, slabs, slab_tot, st);
-    default: return launch_fwd_tm<T, HG_METHOD_INVERSE_QUADRATIC>(d, pl, sym, x, slabs, slab_tot, st);
+    case HG_METHOD_THRESHOLDING: return launch_fwd_tm<T, HG_METHOD_THRESHOLDING>(d, pl, sym, x, pstride, slabs, slab_tot, st);
+    case HG_METHOD_RBF: return launch_fwd_tm<T, HG_METHOD_RBF>(d, pl, sym, x, pstride, slabs, slab_tot, st);
+    default: return launch_fwd_tm<T, HG_METHOD_INVERSE_QUADRATIC>(d, pl, sym, x, pstride, slabs, slab_tot, st);
   }
 }
 
@@ -2035,7 +2102,7 @@ int hg_rgbuv_hist_workspace_bytes(const hg_hist_params *p, size_t *fwd_bytes, si
   const int rc = validate(p);
   if (rc) return rc;
   const Plan pl = make_plan(p);
-  if (fwd_bytes) *fwd_bytes = pl.part_bytes + pl.slab_bytes;
+  if (fwd_bytes) *fwd_bytes = pl.part_bytes + pl.slab_bytes + pl.flag_bytes + pl.proj_bytes;
   if (bwd_bytes) *bwd_bytes = pl.gxs_bytes + pl.gh_bytes;
   return HG_OK;
 }
@@ -2046,7 +2113,7 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
   if (rc) return rc;
   if (!x || !hist_out || !sum_out || !workspace) return HG_EINVAL;
   const Plan pl = make_plan(p);
-  if (workspace_bytes < pl.part_bytes + pl.slab_bytes) return HG_EWORKSPACE;
+  if (workspace_bytes < pl.part_bytes + pl.slab_bytes + pl.flag_bytes + pl.proj_bytes) return HG_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const DevParams d = make_dev(p);
   float *slabs = (float *)((char *)workspace + pl.part_bytes);
@@ -2064,6 +2131,7 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
     }
     const dim3 grid(pl.S_fwd, d.B), block(all3 ? 1024 : 256);
     double *slab_tot = (double *)workspace;
+    bool lean_flags = false;
     if (R) {
       if (all3) hipLaunchKernelGGL(k_hist_rbf_fwd<true>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk, R);
       else hipLaunchKernelGGL(k_hist_rbf_fwd<false>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk, R);
@@ -2075,23 +2143,36 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
         hipError_t e = hipFuncSetAttribute(lk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
       }
-      if (dir && sym) hipLaunchKernelGGL((k_thr_fwd_lean<true, true>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
-      else if (dir) hipLaunchKernelGGL((k_thr_fwd_lean<true, false>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
-      else if (sym) hipLaunchKernelGGL((k_thr_fwd_lean<false, true>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
-      else hipLaunchKernelGGL((k_thr_fwd_lean<false, false>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
+      // S > 1: the last-arriving workgroup of every image sums the slabs itself (HG_THR_ONE_LAUNCH=0: k_hist_finish does)
+      static const bool one_launch = !(getenv("HG_THR_ONE_LAUNCH") && atoi(getenv("HG_THR_ONE_LAUNCH")) == 0);
+      unsigned long long *flags = (pl.S_fwd > 1 && one_launch)
+                                      ? (unsigned long long *)((char *)workspace + pl.part_bytes + pl.slab_bytes) : nullptr;
+      lean_flags = flags != nullptr;
+      static std::atomic<unsigned long long> ctr{0x51ED270B9F3C6A11ull};
+      const unsigned long long tag = ctr.fetch_add(2, std::memory_order_relaxed) | 1ull;
+      if (dir && sym) hipLaunchKernelGGL((k_thr_fwd_lean<true, true>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex, flags, tag);
+      else if (dir) hipLaunchKernelGGL((k_thr_fwd_lean<true, false>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex, flags, tag);
+      else if (sym) hipLaunchKernelGGL((k_thr_fwd_lean<false, true>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex, flags, tag);
+      else hipLaunchKernelGGL((k_thr_fwd_lean<false, false>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex, flags, tag);
     } else {
       if (all3) hipLaunchKernelGGL(k_hist_thr_fwd<true>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk);
       else hipLaunchKernelGGL(k_hist_thr_fwd<false>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk);
     }
     HG_LAUNCH_CHECK();
-    if (!R && thr_lean(p) && pl.S_fwd == 1) return HG_OK;          // normalised in the scatter kernel
+    if (!R && thr_lean(p) && (pl.S_fwd == 1 || lean_flags)) return HG_OK;   // normalised in the scatter kernel
     hipLaunchKernelGGL(k_hist_finish, dim3(pl.nparts, d.B), dim3(256), 0, st, slabs, slab_tot, hist_out, sum_out,
                        pl.S_fwd, pl.S_fwd, d.P * d.h * d.h);
     HG_LAUNCH_CHECK();
     return HG_OK;
   } else {
     double *slab_tot = (double *)workspace;
-    int r = (pl.T == 1) ? launch_fwd_t<1>(d, pl, sym, x, slabs, slab_tot, st) : launch_fwd_t<2>(d, pl, sym, x, slabs, slab_tot, st);
+    // projection pre-pass: into the caller's proj_cache (32 B / pixel, read again by the backward) or into the workspace
+    float4 *proj = d.cache ? d.cache : (float4 *)((char *)workspace + pl.part_bytes + pl.slab_bytes + pl.flag_bytes);
+    const int pstride = d.cache ? 2 : 1;
+    hipLaunchKernelGGL(k_hist_project, dim3((d.npix + 255) / 256, d.B), dim3(256), 0, st, d, x, proj, pstride);
+    HG_LAUNCH_CHECK();
+    int r = (pl.T == 1) ? launch_fwd_t<1>(d, pl, sym, proj, pstride, slabs, slab_tot, st)
+                        : launch_fwd_t<2>(d, pl, sym, proj, pstride, slabs, slab_tot, st);
     if (r) return r;
   }
   // slab sum + normalisation in one launch (the MFMA kernel left every workgroup's share of the image total)

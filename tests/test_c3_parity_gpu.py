@@ -245,25 +245,35 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
         rec['values']['gp'] = truth['gp']
         assert rec['gp'] <= 1e-4, rec
 
-    # discriminator gradients of the D phase (still in its flat gradient buffer; the G phase does not touch them)
-    worst_d, off = (0.0, None), 0
+    # discriminator gradients of the D phase (still in its flat gradient buffer; the G phase does not touch them).  On
+    # gradient-penalty steps they are second-order terms through the LeakyReLU masks: a pre-activation within fp32
+    # rounding of zero flips its mask in ANY fp32 evaluation, and at B = 2 one pixel of a 16 x 16 map is ~1/500 of a
+    # weight's gradient -- so, as for the generator side, the bar is the fp32 reference's own distance to the fp64 truth.
+    worst_d, off, od, rd = (-1.0, ''), 0, [], []
     for prm in GAN._flat_d.params:
         n = prm.numel()
         name = next(k for k, v in GAN.D.named_parameters() if v is prm)
-        worst_d = max(worst_d, (_rel(GAN._flat_d.grad[off:off + n].view(prm.shape), truth['grads'][('D', name)]), name))
+        mine = GAN._flat_d.grad[off:off + n].view(prm.shape)
+        t = truth['grads'][('D', name)]
+        worst_d = max(worst_d, (_rel(mine, t), name), key=lambda v: v[0])
+        od.append((mine.double() - t).flatten()); rd.append((ref32['grads'][('D', name)].double() - t).flatten())
         off += n
+    tnd = torch.cat([t.flatten() for pk, t in truth['grads'].items() if pk[0] == 'D']).norm().clamp_min(1e-300)
     rec['d_grad_worst_ours'], rec['d_grad_worst_name'] = worst_d
     rec['d_grad_worst_ref32'] = max(_rel(ref32['grads'][pk], t) for pk, t in truth['grads'].items() if pk[0] == 'D')
-    assert worst_d[0] <= 1e-4, worst_d
+    rec['d_grad_rms_ours'], rec['d_grad_rms_ref32'] = float(torch.cat(od).norm() / tnd), float(torch.cat(rd).norm() / tnd)
+    _record(f'train_step/{"gp+pl" if pl else "gp" if gp else "plain"}', rec)
+    assert worst_d[0] <= max(1e-4, 2 * rec['d_grad_worst_ref32']), rec
+    assert rec['d_grad_rms_ours'] <= 2 * rec['d_grad_rms_ref32'] + 1e-7, rec
 
     # generator-side gradients are still in the flat buffer (zeroed at the start of the next step)
-    ours_g, ref_g, worst_g = [], [], (0.0, None)
+    ours_g, ref_g, worst_g = [], [], (-1.0, '')
     for (p, k), t in truth['grads'].items():
         if p == 'D':
             continue
         mine = dict(getattr(GAN, p).named_parameters())[k].grad.detach()
         ours_g.append((mine.double() - t).flatten()); ref_g.append((ref32['grads'][(p, k)].double() - t).flatten())
-        worst_g = max(worst_g, (_rel(mine, t), f'{p}.{k}'))
+        worst_g = max(worst_g, (_rel(mine, t), f'{p}.{k}'), key=lambda v: v[0])
     tn = torch.cat([t.flatten() for (p, k), t in truth['grads'].items() if p != 'D']).norm()
     rec['g_grad_rms_ours'] = float(torch.cat(ours_g).norm() / tn)
     rec['g_grad_rms_ref32'] = float(torch.cat(ref_g).norm() / tn)
