@@ -21,7 +21,6 @@
 //
 // Pixel tiles are NI images x TH rows x TW columns (all powers of two, chosen on the host per layer:
 // 32-wide rows for big maps, several whole images per tile for 4x4 / 8x8 maps).
-#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include "hg_common.h"
@@ -78,11 +77,6 @@ struct ConvArgs {
   int ntx, wrow0, wrow_dy, wrow_dx;  // packed-weight row of tap t = wrow0 + (t / ntx)*wrow_dy + (t % ntx)*wrow_dx
   int ksplit;      // > 1: blockIdx.z handles a K range and writes raw partial sums to slab[z] (out layout)
   float *slab;
-  // In-kernel combination of the K-split slabs (no k_splitk_reduce launch): flags[tile][z] = tag once block z of a tile
-  // has written its slab; the block that then finds all ksplit flags of its tile set sums the slabs in z order, applies the
-  // epilogue and clears the flags.  `tag` is unique per launch (never 0), so the flag words need no initialisation.
-  unsigned long long *flags;
-  unsigned long long tag;
   // fused generator epilogue (hg_modconv2d_fwd): v = acc*oscale + bias[n] + noise_w[n]*noise_img[b][y][x]; lrelu
   const float *noise_w, *noise_img;
   int noise_S;     // noise_img is (B, noise_S, noise_S)
@@ -440,96 +434,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, con
     }
   }
   };
-  if (a.ksplit == 1) {
-    epilogue(true);
-    return;
-  }
-  epilogue(false);
-  if (a.flags == nullptr) return;    // the host sums the slabs with k_splitk_reduce
-
-  // ---- last-arriving block of this tile: combine the slabs ("K split without a second launch")
-  __threadfence();                   // this thread's slab stores are visible device-wide ...
-  __syncthreads();                   // ... for every thread of the block (the operand buffers are dead from here on)
-  int *s_last = reinterpret_cast<int *>(smem);
-  if (tid == 0) {
-    unsigned long long *f = a.flags + ((size_t)bidy * (g.tiles_x * g.tiles_y * g.groups) + bidx) * a.ksplit;
-    __hip_atomic_store(&f[bidz], a.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);     // flag store before flag loads: of two blocks finishing together, one sees both
-    int cnt = 0;
-    for (int z = 0; z < a.ksplit; ++z) cnt += __hip_atomic_load(&f[z], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == a.tag;
-    *s_last = cnt == a.ksplit;
-  }
-  __syncthreads();
-  if (!*s_last) return;
-  __threadfence();                   // acquire: the other blocks' slabs, not stale cache lines
-  {
-    // The tile as a flat (channel, pixel) range over all threads -- k_splitk_reduce's arithmetic restricted to this tile,
-    // independent of the MFMA register layout (reloading the slabs into the accumulators and re-running the epilogue cost the
-    // whole kernel its third block per CU in registers).  16-byte loads where rows allow: four pixels of a row per thread,
-    // ksplit x 16 B in flight per element group; fixed z order: deterministic.
-    const size_t total = (size_t)a.B * N * HWo;
-    constexpr int lMB = MB == 256 ? 8 : (MB == 128 ? 7 : 6);
-    static_assert((1 << lMB) == MB, "pixels per block");
-    auto finish = [&](float v, const int ch, const int b, const int cy, const int cx, const size_t idx) __attribute__((always_inline)) {
-      float add = a.bias ? a.bias[ch] : 0.f;
-      if (a.noise_img) add = fmaf(a.noise_w[ch], a.noise_img[((size_t)b * a.noise_S + cy) * a.noise_S + cx], add);
-      v = a.oscale ? fmaf(v, a.oscale[b * N + ch], add) : v + add;
-      if (a.addend) v += a.addend[idx];
-      if (a.slope > 0.f) v = v > 0.f ? v : a.slope * v;
-      return v;
-    };
-    const bool vec = g.lTW >= 2 && (a.Wo & 3) == 0 && a.os == 1 && (HWo & 3) == 0;
-    if (vec) {
-      for (int e = tid * 4; e < NB * MB; e += NT * 4) {
-        const int cl = e >> lMB, p = e & (MB - 1);
-        const int ch = n0 + cl;
-        const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
-        const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
-        if (ch >= N || b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;     // (Wc == Wo, a multiple of 4: whole groups)
-        const size_t idx = ((size_t)b * N + ch) * HWo + (size_t)cy * a.Wo + cx;
-        // four independent partial sums: four slabs' loads in flight per thread (order fixed by z alone: deterministic)
-        const float *sp = a.slab + idx;
-        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
-        int z = 0;
-        for (; z + 3 < a.ksplit; z += 4) {
-          v0 += *reinterpret_cast<const f32x4 *>(sp + (size_t)z * total);
-          v1 += *reinterpret_cast<const f32x4 *>(sp + (size_t)(z + 1) * total);
-          v2 += *reinterpret_cast<const f32x4 *>(sp + (size_t)(z + 2) * total);
-          v3 += *reinterpret_cast<const f32x4 *>(sp + (size_t)(z + 3) * total);
-        }
-        for (; z < a.ksplit; ++z) v0 += *reinterpret_cast<const f32x4 *>(sp + (size_t)z * total);
-        const f32x4 v = (v0 + v1) + (v2 + v3);
-        f32x4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = finish(v[q], ch, b, cy, cx + q, idx + q);
-        *reinterpret_cast<f32x4 *>(a.out + idx) = o;
-      }
-    } else {
-      for (int e = tid; e < NB * MB; e += NT) {
-        const int cl = e >> lMB, p = e & (MB - 1);
-        const int ch = n0 + cl;
-        const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
-        const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
-        if (ch >= N || b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
-        const int oyy = cy * a.os + a.oy, oxx = cx * a.os + a.ox;
-        const size_t idx = ((size_t)b * N + ch) * HWo + (size_t)oyy * a.Wo + oxx;
-        const float *sp = a.slab + idx;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        int z = 0;
-        for (; z + 3 < a.ksplit; z += 4) {
-          v0 += sp[(size_t)z * total]; v1 += sp[(size_t)(z + 1) * total];
-          v2 += sp[(size_t)(z + 2) * total]; v3 += sp[(size_t)(z + 3) * total];
-        }
-        for (; z < a.ksplit; ++z) v0 += sp[(size_t)z * total];
-        a.out[idx] = finish((v0 + v1) + (v2 + v3), ch, b, oyy, oxx, idx);
-      }
-    }
-  }
-  __syncthreads();
-  if (tid == 0) {                    // leave the flags clear: a replayed hipGraph launches this kernel with the same tag
-    unsigned long long *f = a.flags + ((size_t)bidy * (g.tiles_x * g.tiles_y * g.groups) + bidx) * a.ksplit;
-    for (int z = 0; z < a.ksplit; ++z) __hip_atomic_store(&f[z], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  // split-K partials get their epilogue in k_splitk_reduce.  (Round 3 built the combination into this kernel -- the last-
+  // arriving block of a tile summing the slabs behind arrival flags -- and measured it 15 ms per step SLOWER: the
+  // device-scope release / acquire fences it needs write back and invalidate the XCD's whole L2, per block, under the
+  // other blocks' operand reuse.  DESIGN.md section 8.)
+  epilogue(a.ksplit == 1);
 }
 
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM, int MT, bool FE>
@@ -1229,11 +1138,7 @@ ConvPlan plan_conv(int B, int K, int N, int Hc, int Wc, int IS, int os, bool hav
 
 inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st);
 
-// a launch tag: unique per call within the process, never 0
-inline unsigned long long next_conv_tag() {
-  static std::atomic<unsigned long long> ctr{0x9E3779B97F4A7C15ull ^ ((unsigned long long)(uintptr_t)&ctr << 17)};
-  return ctr.fetch_add(2, std::memory_order_relaxed) | 1ull;
-}
+
 
 // output blocks of a plan over B x Hc x Wc compute pixels (before the K split)
 inline long long plan_blocks(const ConvPlan &p, int B, int N, int Hc, int Wc) {
@@ -1300,22 +1205,11 @@ inline int fit_blocks_per_cu(const void *kern, int threads, long long nwg, size_
   return 0;
 }
 
-// ws_bytes: size of the scratch behind a.slab (0: unknown -> no in-kernel combination)
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM = false, int MT = 32>
-int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t st, size_t ws_bytes = 0) {
+int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t st) {
   constexpr int NB = WC * TC * MT, NT = WC * WP * 64;
   size_t lds = prep_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT>(a, tp, ksplit);
   if (!lds) return HG_EUNSUPPORTED;
-  a.flags = nullptr; a.tag = 0;
-  if (ksplit > 1 && reduce) {
-    static const bool inkernel = !(getenv("HG_CONV_SPLITK_INKERNEL") && atoi(getenv("HG_CONV_SPLITK_INKERNEL")) == 0);
-    const size_t slab_b = ((size_t)ksplit * a.B * a.N * a.Ho * a.Wo * sizeof(float) + 255) / 256 * 256;
-    const size_t flag_b = (size_t)a.g.tiles_x * a.g.tiles_y * a.g.groups * ((a.N + NB - 1) / NB) * ksplit * sizeof(unsigned long long);
-    if (inkernel && ws_bytes >= slab_b + flag_b) {
-      a.flags = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.slab) + slab_b);
-      a.tag = next_conv_tag();
-    }
-  }
   const bool fe = a.iscale || a.oscale || a.noise_img || a.slope > 0.f;
   auto kern = fe ? k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, true> : k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, false>;
   static int state[2][2] = {{0, 0}, {0, 0}};
@@ -1326,7 +1220,7 @@ int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t
   const dim3 grid((unsigned)(a.g.tiles_x * a.g.tiles_y * a.g.groups), (unsigned)((a.N + NB - 1) / NB), (unsigned)ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);
   HG_LAUNCH_CHECK();
-  if (ksplit > 1 && reduce && a.flags == nullptr) return launch_splitk_reduce(a, ksplit, st);
+  if (ksplit > 1 && reduce) return launch_splitk_reduce(a, ksplit, st);
   return HG_OK;
 }
 
@@ -1340,7 +1234,6 @@ int launch_conv_parity4(const ConvArgs (&base)[4], const Taps (&tp)[4], int kspl
   int tiles_max = 0;
   for (int c = 0; c < 4; ++c) {
     a4.c[c] = base[c];
-    a4.c[c].flags = nullptr; a4.c[c].tag = 0;    // the caller sums the slabs of the four classes
     a4.tiles[c] = 0;
     if (base[c].Hc <= 0 || base[c].Wc <= 0) continue;   // empty class (1-pixel-wide image)
     size_t l = c == 0 ? prep_conv<WC, WP, TC, TP, 1, KC, 1, SM, MT>(a4.c[c], tp[c], ksplit)
@@ -1364,22 +1257,10 @@ int launch_conv_parity4(const ConvArgs (&base)[4], const Taps (&tp)[4], int kspl
   return HG_OK;
 }
 
-// K-split scratch: ksplit slabs in `out` layout, then (256-byte aligned) one 64-bit flag per (output tile, split) for the
-// in-kernel combination.  Hc x Wc: the compute grid of the launch (== Ho x Wo for stride-1 / forward launches).
 inline size_t conv_slab_bytes(const ConvPlan &p, int B, int N, int Ho, int Wo) {
-  return p.ksplit > 1 ? ((size_t)p.ksplit * B * N * Ho * Wo * sizeof(float) + 255) / 256 * 256 : 0;
+  return p.ksplit > 1 ? (size_t)p.ksplit * B * N * Ho * Wo * sizeof(float) : 0;
 }
-inline size_t conv_flag_bytes(const ConvPlan &p, int B, int N, int Hc, int Wc) {
-  if (p.ksplit <= 1) return 0;
-  const int nbt = p.tile == TILE_16x256 ? 16 : p.tile == TILE_32x256 ? 32 : (p.tile == TILE_64x256 || p.tile == TILE_64x64) ? 64 : 128;
-  const int mbt = (p.tile == TILE_128x128 || p.tile == TILE_128x128_SM) ? 128 : p.tile == TILE_64x64 ? 64 : 256;
-  const int min_t = (p.tile == TILE_128x128_SM || p.tile == TILE_64x64) ? 2 : 4;
-  return (size_t)pixel_tiles(mbt, B, Hc, Wc, min_t) * ((N + nbt - 1) / nbt) * p.ksplit * sizeof(unsigned long long);
-}
-inline size_t conv_ws_bytes(const ConvPlan &p, int B, int N, int Ho, int Wo) {
-  return conv_slab_bytes(p, B, N, Ho, Wo) + conv_flag_bytes(p, B, N, Ho, Wo);
-}
-
+inline size_t conv_ws_bytes(const ConvPlan &p, int B, int N, int Ho, int Wo) { return conv_slab_bytes(p, B, N, Ho, Wo); }
 
 inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st) {
   const long long total = (long long)a.B * a.N * a.Ho * a.Wo;
@@ -1417,11 +1298,11 @@ int dispatch_conv(ConvArgs a, const Taps &tp, void *ws, size_t ws_bytes, hipStre
       return launch_conv<1, 4, 1, 4, TAPS, 4, IS, false, 16>(a, tp, 1, true, st);
     case TILE_32x256: return launch_conv<1, 4, 1, 2, TAPS, KC, IS>(a, tp, 1, true, st);
     case TILE_64x256: return launch_conv<1, 4, 2, 2, TAPS, KC, IS>(a, tp, 1, true, st);
-    case TILE_128x128: return launch_conv<2, 2, 2, 2, TAPS, KC, IS>(a, tp, p.ksplit, true, st, ws_bytes);
+    case TILE_128x128: return launch_conv<2, 2, 2, 2, TAPS, KC, IS>(a, tp, p.ksplit, true, st);
     case TILE_128x128_SM:
-      if constexpr (IS == 1) return launch_conv<2, 2, 2, 2, TAPS, KC, IS, true>(a, tp, p.ksplit, true, st, ws_bytes);
+      if constexpr (IS == 1) return launch_conv<2, 2, 2, 2, TAPS, KC, IS, true>(a, tp, p.ksplit, true, st);
       else return HG_EUNSUPPORTED;
-    default: return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, true>(a, tp, p.ksplit, true, st, ws_bytes);
+    default: return launch_conv<2, 2, 1, 1, TAPS, 2 * KC, IS, true>(a, tp, p.ksplit, true, st);
   }
 }
 

@@ -28,7 +28,6 @@
 // v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain (no reduced-precision path on gfx950).
 #include "hg_common.h"
 #include "../../include/hg_hist.h"
-#include <atomic>
 #include <cstdlib>
 
 #define HG_VERSION_NUM 102   // 102: hg_hist_params.struct_size (ABI guard), hg_rgbuv_hist_uses_proj_cache
@@ -1344,8 +1343,7 @@ template <bool DIRECT, bool SYM>
 __global__ __launch_bounds__(1024) void k_thr_fwd_lean(const DevParams P, const float *__restrict__ x,
                                                        float *__restrict__ slabs, double *__restrict__ slab_tot,
                                                        float *__restrict__ hist, float *__restrict__ sum_out,
-                                                       int per_block, const bool exact_only,
-                                                       unsigned long long *__restrict__ flags, const unsigned long long tag) {
+                                                       int per_block, const bool exact_only) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ unsigned long long sm_tot[16];
   unsigned long long *bins = reinterpret_cast<unsigned long long *>(smem);   // [3][h][h]
@@ -1434,56 +1432,6 @@ __global__ __launch_bounds__(1024) void k_thr_fwd_lean(const DevParams P, const 
   }
   tot = block_sum_u64<1024>(tot, sm_tot);
   if (threadIdx.x == 0) slab_tot[b * S + s] = (double)tot * (1.0 / kThrScale);
-  if (flags == nullptr) return;      // k_hist_finish sums the slabs
-
-  // ---- ONE launch per direction at batch 32 too: the workgroup that finds all S slabs of its image written sums them (slab
-  // order, exactly k_hist_finish's arithmetic), normalises and writes the histogram.  flags[b][s] = tag (unique per launch,
-  // never 0: no initialisation needed) marks slab (b, s) as written; of two workgroups finishing together at least one
-  // sees both flags (release store, seq_cst fence, acquire loads) -- if both do, both write the same values.  Nobody waits.
-  __threadfence();
-  __syncthreads();
-  int *s_last = reinterpret_cast<int *>(sm_tot);
-  if (threadIdx.x == 0) {
-    unsigned long long *f = flags + (size_t)b * S;
-    __hip_atomic_store(&f[s], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    int cnt = 0;
-    for (int z = 0; z < S; ++z) cnt += __hip_atomic_load(&f[z], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == tag;
-    *s_last = cnt == S;
-  }
-  __syncthreads();
-  if (!*s_last) return;
-  __threadfence();
-  {
-    const double *tp = slab_tot + (size_t)b * S;
-    double tsum = 0.0;
-    for (int z = 0; z < S; ++z) tsum += tp[z];
-    const float den = (float)tsum + kEps;
-    if (threadIdx.x == 0) sum_out[b] = den;
-    const float *src = slabs + (size_t)b * S * 3 * hh;
-    float *dst = hist + (size_t)b * 3 * hh;
-    const int nel = 3 * hh, nq2 = nel >> 2;
-    if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0 && (nel & 3) == 0) {
-      for (int e4 = threadIdx.x; e4 < nq2; e4 += 1024) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int z = 0; z < S; ++z) {
-          const float4 t = reinterpret_cast<const float4 *>(src + (size_t)z * nel)[e4];
-          v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
-        reinterpret_cast<float4 *>(dst)[e4] = make_float4(v.x / den, v.y / den, v.z / den, v.w / den);
-      }
-    } else {
-      for (int e = threadIdx.x; e < nel; e += 1024) {
-        float v = 0.f;
-        for (int z = 0; z < S; ++z) v += src[(size_t)z * nel + e];
-        dst[e] = v / den;
-      }
-    }
-  }
-  if (threadIdx.x == 0) {            // flags clear again: a replayed hipGraph re-launches with the same tag
-    unsigned long long *f = flags + (size_t)b * S;
-    for (int z = 0; z < S; ++z) __hip_atomic_store(&f[z], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 // One-launch backward: <G, out> is rebuilt per workgroup (2 x 48 KB from L2, as k_hist_bwd does) instead of a
@@ -1828,7 +1776,6 @@ struct Plan {
   int nparts;                // reduce blocks per image
   int S_bwd, rounds;         // backward: WGs per image, 32-pixel rounds per wave
   size_t slab_bytes, part_bytes, gh_bytes, gxs_bytes;
-  size_t flag_bytes;         // forward: one 64-bit arrival flag per (image, split) behind the slabs (lean scatter path)
   size_t proj_bytes;         // forward, dense path: (a, b, c, Iy) per pixel from the projection pre-pass (16 B / pixel)
   int planes_rt;             // > 0: backward on k_hist_bwd_planes<planes_rt> (see bwd_planes_rt)
 };
@@ -1928,7 +1875,6 @@ Plan make_plan(const hg_hist_params *p) {
   const long long n_per_img = (long long)P * p->h * p->h;
   pl.nparts = (int)((n_per_img + 1023) / 1024);
   pl.slab_bytes = ((size_t)p->B * S * n_per_img * sizeof(float) + 255) / 256 * 256;
-  pl.flag_bytes = ((size_t)p->B * S * sizeof(unsigned long long) + 255) / 256 * 256;
   pl.proj_bytes = sparse_path(p) ? 0 : ((size_t)p->B * npix * sizeof(float4) + 255) / 256 * 256;
   pl.part_bytes = ((size_t)p->B * pl.nparts * sizeof(float) + 255) / 256 * 256;
   // slab_tot[B][S (x bin blocks)] doubles for k_hist_finish
@@ -2102,7 +2048,7 @@ int hg_rgbuv_hist_workspace_bytes(const hg_hist_params *p, size_t *fwd_bytes, si
   const int rc = validate(p);
   if (rc) return rc;
   const Plan pl = make_plan(p);
-  if (fwd_bytes) *fwd_bytes = pl.part_bytes + pl.slab_bytes + pl.flag_bytes + pl.proj_bytes;
+  if (fwd_bytes) *fwd_bytes = pl.part_bytes + pl.slab_bytes + pl.proj_bytes;
   if (bwd_bytes) *bwd_bytes = pl.gxs_bytes + pl.gh_bytes;
   return HG_OK;
 }
@@ -2113,7 +2059,7 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
   if (rc) return rc;
   if (!x || !hist_out || !sum_out || !workspace) return HG_EINVAL;
   const Plan pl = make_plan(p);
-  if (workspace_bytes < pl.part_bytes + pl.slab_bytes + pl.flag_bytes + pl.proj_bytes) return HG_EWORKSPACE;
+  if (workspace_bytes < pl.part_bytes + pl.slab_bytes + pl.proj_bytes) return HG_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const DevParams d = make_dev(p);
   float *slabs = (float *)((char *)workspace + pl.part_bytes);
@@ -2131,7 +2077,6 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
     }
     const dim3 grid(pl.S_fwd, d.B), block(all3 ? 1024 : 256);
     double *slab_tot = (double *)workspace;
-    bool lean_flags = false;
     if (R) {
       if (all3) hipLaunchKernelGGL(k_hist_rbf_fwd<true>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk, R);
       else hipLaunchKernelGGL(k_hist_rbf_fwd<false>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk, R);
@@ -2143,23 +2088,19 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
         hipError_t e = hipFuncSetAttribute(lk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
       }
-      // S > 1: the last-arriving workgroup of every image sums the slabs itself (HG_THR_ONE_LAUNCH=0: k_hist_finish does)
-      static const bool one_launch = !(getenv("HG_THR_ONE_LAUNCH") && atoi(getenv("HG_THR_ONE_LAUNCH")) == 0);
-      unsigned long long *flags = (pl.S_fwd > 1 && one_launch)
-                                      ? (unsigned long long *)((char *)workspace + pl.part_bytes + pl.slab_bytes) : nullptr;
-      lean_flags = flags != nullptr;
-      static std::atomic<unsigned long long> ctr{0x51ED270B9F3C6A11ull};
-      const unsigned long long tag = ctr.fetch_add(2, std::memory_order_relaxed) | 1ull;
-      if (dir && sym) hipLaunchKernelGGL((k_thr_fwd_lean<true, true>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex, flags, tag);
-      else if (dir) hipLaunchKernelGGL((k_thr_fwd_lean<true, false>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex, flags, tag);
-      else if (sym) hipLaunchKernelGGL((k_thr_fwd_lean<false, true>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex, flags, tag);
-      else hipLaunchKernelGGL((k_thr_fwd_lean<false, false>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex, flags, tag);
+      // (S > 1: k_hist_finish sums the slabs.  Round 3 tried ONE launch -- the last-arriving workgroup of an image, found
+      // through arrival flags, summing them -- and measured 152 us instead of 22: the device-scope release / acquire fences
+      // that make another XCD's slabs visible write back and invalidate whole L2s, once per wave of every workgroup.)
+      if (dir && sym) hipLaunchKernelGGL((k_thr_fwd_lean<true, true>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
+      else if (dir) hipLaunchKernelGGL((k_thr_fwd_lean<true, false>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
+      else if (sym) hipLaunchKernelGGL((k_thr_fwd_lean<false, true>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
+      else hipLaunchKernelGGL((k_thr_fwd_lean<false, false>), grid, block, lds, st, d, x, slabs, slab_tot, hist_out, sum_out, 4 * pl.chunk, ex);
     } else {
       if (all3) hipLaunchKernelGGL(k_hist_thr_fwd<true>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk);
       else hipLaunchKernelGGL(k_hist_thr_fwd<false>, grid, block, lds, st, d, x, slabs, slab_tot, 4 * pl.chunk);
     }
     HG_LAUNCH_CHECK();
-    if (!R && thr_lean(p) && (pl.S_fwd == 1 || lean_flags)) return HG_OK;   // normalised in the scatter kernel
+    if (!R && thr_lean(p) && pl.S_fwd == 1) return HG_OK;          // normalised in the scatter kernel
     hipLaunchKernelGGL(k_hist_finish, dim3(pl.nparts, d.B), dim3(256), 0, st, slabs, slab_tot, hist_out, sum_out,
                        pl.S_fwd, pl.S_fwd, d.P * d.h * d.h);
     HG_LAUNCH_CHECK();
@@ -2167,7 +2108,7 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
   } else {
     double *slab_tot = (double *)workspace;
     // projection pre-pass: into the caller's proj_cache (32 B / pixel, read again by the backward) or into the workspace
-    float4 *proj = d.cache ? d.cache : (float4 *)((char *)workspace + pl.part_bytes + pl.slab_bytes + pl.flag_bytes);
+    float4 *proj = d.cache ? d.cache : (float4 *)((char *)workspace + pl.part_bytes + pl.slab_bytes);
     const int pstride = d.cache ? 2 : 1;
     hipLaunchKernelGGL(k_hist_project, dim3((d.npix + 255) / 256, d.B), dim3(256), 0, st, d, x, proj, pstride);
     HG_LAUNCH_CHECK();

@@ -288,10 +288,9 @@ def test_lrelu_bwd_channel_sum_matches_aten(shape, gpu_device):
 
 
 @pytest.mark.parametrize('B,K,N,H', [(32, 2048, 1024, 8), (16, 2048, 2048, 4), (64, 1024, 2048, 2), (32, 1024, 512, 16)])
-def test_splitk_launches_combine_in_kernel_deterministically(B, K, N, H, gpu_device):
-    """K-split launches (few pixels, many channels) sum their slabs in the last-arriving block of every output tile
-    (flags in the workspace, no second launch): the plan says K split > 1, results repeat bit for bit (fixed z order,
-    whichever block arrives last) and match fp64; a forward and a data gradient."""
+def test_splitk_launches_are_deterministic_and_exact(B, K, N, H, gpu_device):
+    """K-split launches (few pixels, many channels: the plan says K split > 1) sum their slabs in fixed z order
+    (k_splitk_reduce): results repeat bit for bit and match fp64; a forward and a data gradient."""
     import ctypes
     from histogan_amd._lib import lib
     from histogan_amd.conv import conv2d_same
