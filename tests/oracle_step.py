@@ -134,3 +134,26 @@ def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hi
     out['grads'] = grads
     out['params'] = {(p, k): v.detach() for p, s in [('D', out['params_d'])] + groups for k, v in s.items()}
     return out
+
+
+def lrelu_margin(sd_d, images, nblk):
+    """Smallest |pre-activation| of any LeakyReLU of the discriminator on `images`, relative to its layer's largest, evaluated
+    in fp64.  A pre-activation within fp32 rounding of zero (~1e-7 relative) gets the other LeakyReLU slope in ANY fp32
+    evaluation -- ours, aten's -- than in fp64; the gradient penalty's second-order terms then differ by that one pixel's
+    whole contribution (at B = 2 ~1e-2 of a weight gradient; measured: element [1, 3, 19, 25] of blocks.3.net.2, |pre| / max
+    = 1.3e-9, tools/debug_gp4.py).  Tests that hold discriminator gradients of a gradient-penalty step to 1e-4 pick input
+    data whose margin is well above fp32 resolution."""
+    sd = {k: v.detach().double() for k, v in sd_d.items()}
+    x = images.detach().double()
+    m = 1.0
+    for i in range(nblk):
+        p = f'blocks.{i}.'
+        pre = F.conv2d(x, sd[p + 'net.0.weight'], sd[p + 'net.0.bias'], padding=1)
+        m = min(m, float(pre.abs().min() / pre.abs().max()))
+        h = F.leaky_relu(pre, 0.2)
+        pre = F.conv2d(h, sd[p + 'net.2.weight'], sd[p + 'net.2.bias'], padding=1)
+        m = min(m, float(pre.abs().min() / pre.abs().max()))
+        x = F.leaky_relu(pre, 0.2) + F.conv2d(x, sd[p + 'conv_res.weight'], sd[p + 'conv_res.bias'])
+        if p + 'downsample.weight' in sd:
+            x = F.conv2d(x, sd[p + 'downsample.weight'], sd[p + 'downsample.bias'], padding=1, stride=2)
+    return m

@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import ROOT, relmax
-from oracle_step import ReplayRng, oracle_train_step
+from oracle_step import ReplayRng, lrelu_margin, oracle_train_step
 
 pytestmark = pytest.mark.gpu
 
@@ -215,18 +215,27 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
             blk.to_noise1.weight.normal_(std=0.3); blk.to_noise2.weight.normal_(std=0.3)
     L = GAN.G.num_layers
     sd0 = {k: v.detach().clone() for k, v in GAN.state_dict().items()}
-    gen = torch.Generator().manual_seed(6)
-    batches = []
-    for _ in range(2):
-        img = torch.rand(B, 3, S_, S_, generator=gen)
-        hist = OH.rgbuv_hist(torch.rand(B, 3, S_, S_, generator=gen), h=HB)
-        batches.append({'images': img.to(dev), 'histograms': hist.to(dev)})
+    gp, pl = step_no % 4 == 0, step_no % 32 == 0
+    # real images whose LeakyReLU pre-activations all stay clear of zero in fp64 (oracle_step.lrelu_margin): with the first
+    # candidate seed one of the 7.9e6 pre-activations is 1.3e-9 of its layer's maximum, and every fp32 evaluation takes
+    # the other slope there than fp64 -- a 1e-2 difference in one weight gradient of the penalty's second-order terms
+    sd_d = {k[2:]: v for k, v in sd0.items() if k.startswith('D.')}
+    for data_seed in range(6, 26):
+        gen = torch.Generator().manual_seed(data_seed)
+        batches = []
+        for _ in range(2):
+            img = torch.rand(B, 3, S_, S_, generator=gen)
+            hist = OH.rgbuv_hist(torch.rand(B, 3, S_, S_, generator=gen), h=HB)
+            batches.append({'images': img.to(dev), 'histograms': hist.to(dev)})
+        margin = lrelu_margin(sd_d, batches[0]['images'], L + 1)
+        if not gp or margin > 2e-6:
+            break
+    assert not gp or margin > 2e-6, margin
     tr.loader = iter(batches)
     tr.rng = ReplayRng(dev, B, L, LAT, S_, 78, tt=2)
     tr.steps = step_no
     tr.train(alpha=ALPHA)
     new = {k: v.detach() for k, v in GAN.state_dict().items()}
-    gp, pl = step_no % 4 == 0, step_no % 32 == 0
 
     # the G phase of both oracle runs scores the fakes with the discriminator the product path used (see oracle_step.py:
     # the first DiffGrad step is sign-like, its result ill-conditioned wherever a gradient is rounding noise)
@@ -236,7 +245,7 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
     ref32 = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, 78, tt=2), L, HB, ALPHA, LR, gp, pl,
                               d_override=d_used)
     rel = lambda a, b: abs(a - b) / max(1.0, abs(b))      # the un-normalised logits are >> 1 at this capacity
-    rec = dict(d_loss=rel(tr.d_loss, truth['d_loss']), g_loss=rel(tr.g_loss, truth['g_loss']),
+    rec = dict(data_seed=data_seed, lrelu_margin=margin, d_loss=rel(tr.d_loss, truth['d_loss']), g_loss=rel(tr.g_loss, truth['g_loss']),
                h_loss=abs(tr.h_loss - truth['h_loss']), values=dict(d=truth['d_loss'], g=truth['g_loss'], h=truth['h_loss']),
                g_loss_ref32=rel(ref32['g_loss'], truth['g_loss']))
     assert rec['d_loss'] <= 1e-4 and rec['g_loss'] <= 1e-4 and rec['h_loss'] <= 1e-4, rec
@@ -246,9 +255,8 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
         assert rec['gp'] <= 1e-4, rec
 
     # discriminator gradients of the D phase (still in its flat gradient buffer; the G phase does not touch them).  On
-    # gradient-penalty steps they are second-order terms through the LeakyReLU masks: a pre-activation within fp32
-    # rounding of zero flips its mask in ANY fp32 evaluation, and at B = 2 one pixel of a 16 x 16 map is ~1/500 of a
-    # weight's gradient -- so, as for the generator side, the bar is the fp32 reference's own distance to the fp64 truth.
+    # gradient-penalty steps they are the penalty's second-order terms through the LeakyReLU masks (the data above keeps
+    # every pre-activation clear of zero, so fp32 and fp64 evaluations take the same slopes): 1e-4 per tensor.
     worst_d, off, od, rd = (-1.0, ''), 0, [], []
     for prm in GAN._flat_d.params:
         n = prm.numel()

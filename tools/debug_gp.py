@@ -18,7 +18,9 @@ S_, CAP, HB, LAT, B = 256, 16, 64, 512, 2
 dev = torch.device('cuda:0')
 
 
-def run(tag, side, fused_lrelu=True, conv_add=True):
+def run(tag, side, fused_lrelu=True, conv_add=True, overlap=True, packcache=True):
+    import histogan_amd.trainer as T
+    T.G_OVERLAP = overlap
     C.SIDE_WGRAD = side
     torch.manual_seed(31)
     tmp = tempfile.mkdtemp()
@@ -27,6 +29,8 @@ def run(tag, side, fused_lrelu=True, conv_add=True):
     tr.graph_mode = '0'
     tr.run_evaluate = tr.run_save = False
     tr.init_GAN()
+    if not packcache:
+        C.enable_pack_cache(None)
     GAN = tr.GAN
     L = GAN.G.num_layers
     sd0 = {k: v.detach().clone() for k, v in GAN.state_dict().items()}
@@ -57,8 +61,8 @@ def run(tag, side, fused_lrelu=True, conv_add=True):
 
 
 sd0, batches, L, gA = run('direct', True)
-_, _, _, gB = run('autograd', False)
-_, _, _, gC = run('direct_aten_lrelu', True, fused_lrelu=False)
+_, _, _, gB = run('no_overlap', True, overlap=False)
+_, _, _, gC = run('no_packcache', True, packcache=False)
 truth = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, 78, tt=2, dtype=torch.float64), L, HB, 2.0, 2e-4, True,
                           False, optimizer=False)
 rel = lambda a, t: float((a.double() - t).abs().max() / t.abs().max().clamp_min(1e-300))
@@ -67,7 +71,7 @@ for name in gA:
     t = truth['grads'][('D', name)]
     rows.append((rel(gA[name], t), rel(gB[name], t), rel(gC[name], t), name, tuple(t.shape)))
 rows.sort(reverse=True)
-print('direct        autograd      direct+aten_lrelu   name')
+print('direct        no G overlap  no pack cache   name')
 for r in rows[:14]:
     print(f'{r[0]:.3e}    {r[1]:.3e}    {r[2]:.3e}    {r[3]} {r[4]}')
 w = rows[0][3]
