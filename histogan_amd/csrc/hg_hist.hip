@@ -210,30 +210,12 @@ __device__ __forceinline__ void lds_wave_sync() {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Projection pre-pass of the dense forward: clamp / resize / three fp64 logarithms per pixel (~370 VALU instructions) at full
-// occupancy in a kernel of its own, 16 (or 32: with the backward's colour record) bytes per pixel out.  Inside k_hist_fwd
-// that work cost matrix-pipe time -- fp32 MFMA and VALU share the issue path on gfx950 (tools/ubench/mfma_valu_overlap.hip):
-// 3.3 non-MFMA VALU instructions per MFMA, a third of them the projection (profiles/r02_hist_pmc_raw.txt).
-// dst[(b*npix + n)*pstride] = (a, b, c, Iy); pstride == 2: dst[.. + 1] = (r, g, b, 0) (hg_hist_params.proj_cache layout).
-__global__ __launch_bounds__(256) void k_hist_project(const DevParams P, const float *__restrict__ x,
-                                                      float4 *__restrict__ dst, const int pstride) {
-  const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= P.npix) return;
-  float r, g, bl, a, bb, c, iy;
-  sample_rgb(P, x + (long long)b * P.sb, n, r, g, bl);
-  project(P, r, g, bl, a, bb, c, iy);
-  float4 *d = dst + ((long long)b * P.npix + n) * pstride;
-  d[0] = make_float4(a, bb, c, iy);
-  if (pstride == 2) d[1] = make_float4(r, g, bl, 0.f);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Forward.  grid = (S splits, nbd*nbd output blocks, B images), 256 threads = 4 independent waves.
 // Each wave owns a contiguous run of `chunk` pixels and accumulates a (3 x BLK x BLK) partial
 // histogram block (BLK = 32*T) in 3*T*T MFMA accumulator tiles; the 4 waves are then summed through
 // LDS in fixed order and written as one slab  slabs[b][s][p][h][h]  (real bin order, flips undone).
 template <int T, int METHOD, bool SYM, bool DIAG, bool GREEN>
-__global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const float4 *__restrict__ proj, const int pstride,
+__global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const float *__restrict__ x,
                                                      float *__restrict__ slabs, double *__restrict__ slab_tot,
                                                      const int chunk) {
   constexpr int BLK = 32 * T;
@@ -246,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
   const int nbd = (P.h + BLK - 1) / BLK;
   const int bi = blockIdx.y / nbd, bj = blockIdx.y - bi * nbd;
   const int b = blockIdx.z, s = blockIdx.x, S = gridDim.x;
-  const float4 *pb = proj + (long long)b * P.npix * pstride;   // (a, b, c, Iy) per pixel, from k_hist_project
+  const float *xb = x + (long long)b * P.sb;
 
   // per-lane bin constants: A side = rows (i) of this block, B side = columns (j)
   BinC cA[T], cAm[T], cB[T], cBm[T];
@@ -316,13 +298,23 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
     }
   };
 
-  float4 q_ = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (start + lane < end) q_ = pb[((long long)start + lane) * pstride];
+  // (Round 3 moved the projection -- clamp / resize / three fp64 logarithms, ~370 VALU instructions per pixel, a third of
+  // this kernel's VALU work -- into a pre-pass kernel of its own: k_hist_fwd got 2 % faster (455 -> 446 us at configs[1]),
+  // the pre-pass cost 23 us.  The other wave of the SIMD evidently hides most of it here; it stays in the kernel.)
+  float r_ = 0.f, g_ = 0.f, b_ = 0.f;
+  if (start + lane < end) sample_rgb(P, xb, (int)start + lane, r_, g_, b_);
   for (int base = (int)start; base < end; base += 64) {
+    float a, bb, c, iy;
+    project(P, r_, g_, b_, a, bb, c, iy);
     const bool valid = base + lane < end;
-    stage[wave * 64 + lane] = valid ? q_ : make_float4(0.f, 0.f, 0.f, 0.f);
+    stage[wave * 64 + lane] = valid ? make_float4(a, bb, c, iy) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.cache && valid && blockIdx.y == 0) {          // one writer per pixel (the bin-block replicas skip it)
+      float4 *cp = P.cache + ((long long)b * P.npix + base + lane) * 2;
+      cp[0] = make_float4(a, bb, c, iy);
+      cp[1] = make_float4(r_, g_, b_, 0.f);
+    }
     // prefetch the next 64 pixels while this batch is in the MFMA loop
-    if (base + 64 + lane < end) q_ = pb[((long long)base + 64 + lane) * pstride];
+    if (base + 64 + lane < end) sample_rgb(P, xb, base + 64 + lane, r_, g_, b_);
     lds_wave_sync();
     const int steps = (min(64, end - base) + 1) >> 1;
     // Software-pipelined K loop: the operands of step m+1 (VALU: 3..6 kernel vectors) are generated next to the
@@ -1776,7 +1768,6 @@ struct Plan {
   int nparts;                // reduce blocks per image
   int S_bwd, rounds;         // backward: WGs per image, 32-pixel rounds per wave
   size_t slab_bytes, part_bytes, gh_bytes, gxs_bytes;
-  size_t proj_bytes;         // forward, dense path: (a, b, c, Iy) per pixel from the projection pre-pass (16 B / pixel)
   int planes_rt;             // > 0: backward on k_hist_bwd_planes<planes_rt> (see bwd_planes_rt)
 };
 
@@ -1875,7 +1866,6 @@ Plan make_plan(const hg_hist_params *p) {
   const long long n_per_img = (long long)P * p->h * p->h;
   pl.nparts = (int)((n_per_img + 1023) / 1024);
   pl.slab_bytes = ((size_t)p->B * S * n_per_img * sizeof(float) + 255) / 256 * 256;
-  pl.proj_bytes = sparse_path(p) ? 0 : ((size_t)p->B * npix * sizeof(float4) + 255) / 256 * 256;
   pl.part_bytes = ((size_t)p->B * pl.nparts * sizeof(float) + 255) / 256 * 256;
   // slab_tot[B][S (x bin blocks)] doubles for k_hist_finish
   pl.part_bytes = ((size_t)p->B * S * pl.nbd * pl.nbd * sizeof(double) + 255) / 256 * 256;
@@ -1929,32 +1919,32 @@ DevParams make_dev(const hg_hist_params *p) {
 }
 
 template <int T, int METHOD, bool GREEN>
-int launch_fwd_tmg(const DevParams &d, const Plan &pl, bool sym, const float4 *x, int pstride, float *slabs, double *slab_tot,
+int launch_fwd_tmg(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, double *slab_tot,
                    hipStream_t st) {
   const dim3 grid(pl.S_fwd, pl.nbd * pl.nbd, d.B), block(256);
   const size_t lds = 4 * 64 * 16 + (size_t)3 * pl.BLK * pl.BLK * sizeof(float);
   const bool diag = pl.nbd == 1;
-  if (sym && diag) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, true, GREEN>), grid, block, lds, st, d, x, pstride, slabs, slab_tot, pl.chunk);
-  else if (sym) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, false, GREEN>), grid, block, lds, st, d, x, pstride, slabs, slab_tot, pl.chunk);
-  else hipLaunchKernelGGL((k_hist_fwd<T, METHOD, false, false, GREEN>), grid, block, lds, st, d, x, pstride, slabs, slab_tot, pl.chunk);
+  if (sym && diag) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, true, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
+  else if (sym) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, false, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
+  else hipLaunchKernelGGL((k_hist_fwd<T, METHOD, false, false, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
 
 template <int T, int METHOD>
-int launch_fwd_tm(const DevParams &d, const Plan &pl, bool sym, const float4 *x, int pstride, float *slabs, double *slab_tot,
+int launch_fwd_tm(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, double *slab_tot,
                   hipStream_t st) {
-  return d.green ? launch_fwd_tmg<T, METHOD, true>(d, pl, sym, x, pstride, slabs, slab_tot, st)
-                 : launch_fwd_tmg<T, METHOD, false>(d, pl, sym, x, pstride, slabs, slab_tot, st);
+  return d.green ? launch_fwd_tmg<T, METHOD, true>(d, pl, sym, x, slabs, slab_tot, st)
+                 : launch_fwd_tmg<T, METHOD, false>(d, pl, sym, x, slabs, slab_tot, st);
 }
 
 template <int T>
-int launch_fwd_t(const DevParams &d, const Plan &pl, bool sym, const float4 *x, int pstride, float *slabs, double *slab_tot,
+int launch_fwd_t(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, double *slab_tot,
                  hipStream_t st) {
   switch (d.method) {
-    case HG_METHOD_THRESHOLDING: return launch_fwd_tm<T, HG_METHOD_THRESHOLDING>(d, pl, sym, x, pstride, slabs, slab_tot, st);
-    case HG_METHOD_RBF: return launch_fwd_tm<T, HG_METHOD_RBF>(d, pl, sym, x, pstride, slabs, slab_tot, st);
-    default: return launch_fwd_tm<T, HG_METHOD_INVERSE_QUADRATIC>(d, pl, sym, x, pstride, slabs, slab_tot, st);
+    case HG_METHOD_THRESHOLDING: return launch_fwd_tm<T, HG_METHOD_THRESHOLDING>(d, pl, sym, x, slabs, slab_tot, st);
+    case HG_METHOD_RBF: return launch_fwd_tm<T, HG_METHOD_RBF>(d, pl, sym, x, slabs, slab_tot, st);
+    default: return launch_fwd_tm<T, HG_METHOD_INVERSE_QUADRATIC>(d, pl, sym, x, slabs, slab_tot, st);
   }
 }
 
@@ -2048,7 +2038,7 @@ int hg_rgbuv_hist_workspace_bytes(const hg_hist_params *p, size_t *fwd_bytes, si
   const int rc = validate(p);
   if (rc) return rc;
   const Plan pl = make_plan(p);
-  if (fwd_bytes) *fwd_bytes = pl.part_bytes + pl.slab_bytes + pl.proj_bytes;
+  if (fwd_bytes) *fwd_bytes = pl.part_bytes + pl.slab_bytes;
   if (bwd_bytes) *bwd_bytes = pl.gxs_bytes + pl.gh_bytes;
   return HG_OK;
 }
@@ -2059,7 +2049,7 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
   if (rc) return rc;
   if (!x || !hist_out || !sum_out || !workspace) return HG_EINVAL;
   const Plan pl = make_plan(p);
-  if (workspace_bytes < pl.part_bytes + pl.slab_bytes + pl.proj_bytes) return HG_EWORKSPACE;
+  if (workspace_bytes < pl.part_bytes + pl.slab_bytes) return HG_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const DevParams d = make_dev(p);
   float *slabs = (float *)((char *)workspace + pl.part_bytes);
@@ -2107,13 +2097,7 @@ int hg_rgbuv_hist_fwd(const hg_hist_params *p, const float *x, float *hist_out, 
     return HG_OK;
   } else {
     double *slab_tot = (double *)workspace;
-    // projection pre-pass: into the caller's proj_cache (32 B / pixel, read again by the backward) or into the workspace
-    float4 *proj = d.cache ? d.cache : (float4 *)((char *)workspace + pl.part_bytes + pl.slab_bytes);
-    const int pstride = d.cache ? 2 : 1;
-    hipLaunchKernelGGL(k_hist_project, dim3((d.npix + 255) / 256, d.B), dim3(256), 0, st, d, x, proj, pstride);
-    HG_LAUNCH_CHECK();
-    int r = (pl.T == 1) ? launch_fwd_t<1>(d, pl, sym, proj, pstride, slabs, slab_tot, st)
-                        : launch_fwd_t<2>(d, pl, sym, proj, pstride, slabs, slab_tot, st);
+    int r = (pl.T == 1) ? launch_fwd_t<1>(d, pl, sym, x, slabs, slab_tot, st) : launch_fwd_t<2>(d, pl, sym, x, slabs, slab_tot, st);
     if (r) return r;
   }
   // slab sum + normalisation in one launch (the MFMA kernel left every workgroup's share of the image total)

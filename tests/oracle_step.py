@@ -146,6 +146,7 @@ def lrelu_margin(sd_d, images, nblk):
     sd = {k: v.detach().double() for k, v in sd_d.items()}
     x = images.detach().double()
     m = 1.0
+    # (runs where the images live: on the GPU in the C3 test, ~0.2 s per candidate batch)
     for i in range(nblk):
         p = f'blocks.{i}.'
         pre = F.conv2d(x, sd[p + 'net.0.weight'], sd[p + 'net.0.bias'], padding=1)

@@ -220,7 +220,9 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
     # candidate seed one of the 7.9e6 pre-activations is 1.3e-9 of its layer's maximum, and every fp32 evaluation takes
     # the other slope there than fp64 -- a 1e-2 difference in one weight gradient of the penalty's second-order terms
     sd_d = {k[2:]: v for k, v in sd0.items() if k.startswith('D.')}
-    for data_seed in range(6, 26):
+    # (fp32 conv sums near zero carry ~1e-8 of the layer maximum as rounding error -- eps x sqrt(1152 terms) against a
+    # maximum of ~170 term magnitudes; 5e-8 leaves a factor of four.  About one batch in five has no pre-activation below it.)
+    for data_seed in range(6, 86):
         gen = torch.Generator().manual_seed(data_seed)
         batches = []
         for _ in range(2):
@@ -228,9 +230,9 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
             hist = OH.rgbuv_hist(torch.rand(B, 3, S_, S_, generator=gen), h=HB)
             batches.append({'images': img.to(dev), 'histograms': hist.to(dev)})
         margin = lrelu_margin(sd_d, batches[0]['images'], L + 1)
-        if not gp or margin > 2e-6:
+        if not gp or margin > 5e-8:
             break
-    assert not gp or margin > 2e-6, margin
+    assert not gp or margin > 5e-8, margin
     tr.loader = iter(batches)
     tr.rng = ReplayRng(dev, B, L, LAT, S_, 78, tt=2)
     tr.steps = step_no
