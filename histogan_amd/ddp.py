@@ -53,13 +53,25 @@ def _avg_in_collective():
     return dist.get_backend() == 'nccl'
 
 
+# Buckets per gradient buffer under data parallelism: the all-reduce of bucket i+1 runs (on RCCL's stream) while the
+# optimizer already updates the parameters of bucket i -- DiffGrad is elementwise over the flat buffer, so applying it
+# bucket by bucket is the same update (HG_DDP_BUCKETS=1: one collective, one optimizer launch).
+BUCKETS = max(1, int(os.environ.get('HG_DDP_BUCKETS', '4')))
+
+
 class GradAllReduce:
-    """Averaging all-reduce of a flat gradient buffer, optionally asynchronous."""
+    """Averaging all-reduce of a flat gradient buffer in `chunks` contiguous buckets, asynchronous: `start()` launches all
+    of them in order, `wait(i)` makes the current stream wait for bucket i only (`ranges[i]` = its element range),
+    `finish()` for all."""
 
     def __init__(self, flat, chunks=1):
         self.flat = flat
         self.chunks = max(1, int(chunks))
         self._work = []
+        n, c = flat.numel, self.chunks
+        step = -(-n // c)
+        step = -(-step // 1024) * 1024                      # bucket boundaries on 4 KB
+        self.ranges = [(lo, min(n, lo + step)) for lo in range(0, n, step)]
 
     def start(self):
         self.flat.gather()
@@ -71,12 +83,18 @@ class GradAllReduce:
         else:
             op = dist.ReduceOp.SUM
             g.mul_(1.0 / world_size())
-        for c in g.chunk(self.chunks):
-            self._work.append(dist.all_reduce(c, op=op, async_op=True))
+        for lo, hi in self.ranges:
+            self._work.append(dist.all_reduce(g[lo:hi], op=op, async_op=True))
+
+    def wait(self, i):
+        """The current stream waits for bucket i (no-op when not distributed / already waited for)."""
+        if i < len(self._work) and self._work[i] is not None:
+            self._work[i].wait()
+            self._work[i] = None
 
     def finish(self):
-        for w in self._work:
-            w.wait()
+        for i in range(len(self._work)):
+            self.wait(i)
         self._work = []
 
     def __call__(self):

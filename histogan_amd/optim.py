@@ -132,6 +132,29 @@ class DiffGrad:
         self._step_size_dev.fill_(lib.hg_diffgrad_step_size(float(lr), float(self.betas[0]), float(self.betas[1]),
                                                             self.step_count))
 
+    def step_buckets(self, reducer):
+        """The update bucket by bucket behind a bucketed gradient all-reduce (ddp.GradAllReduce, already started): bucket
+        i's parameters are updated as soon as ITS collective is done, while the later buckets are still on the wire.
+        Elementwise over the flat buffer: the same update as one launch."""
+        f = self.flat
+        f.gather()
+        if not f.data.is_cuda:
+            raise RuntimeError('DiffGrad: parameters are not on a GPU; no CPU implementation')
+        if self.graph_mode:
+            raise RuntimeError('DiffGrad.step_buckets: not available inside a captured graph')
+        self.step_count += 1
+        lr = self.param_groups[0]['lr']
+        with on_device(f.data.device):
+            for i, (lo, hi) in enumerate(reducer.ranges):
+                reducer.wait(i)
+                o = 4 * lo
+                check(lib.hg_diffgrad_step(f.data.data_ptr() + o, f.grad.data_ptr() + o, self.exp_avg.data_ptr() + o,
+                                           self.exp_avg_sq.data_ptr() + o, self.previous_grad.data_ptr() + o, hi - lo,
+                                           float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                           self.step_count, _st(f.data)), 'hg_diffgrad_step')
+        reducer.finish()
+        weights_changed(f.data)
+
     def step(self):
         f = self.flat
         f.gather()

@@ -9,6 +9,12 @@ HistoGAN trainer is (histogan_amd/trainer.py): flat parameter/gradient buffers w
 encoder-decoder + head under no_grad (the reference builds and discards that graph), one `[fake; real]`
 discriminator pass, no D weight gradients in the G phase, one read-back per step, RCCL all-reduce of the flat
 gradient buffers under data parallelism.
+
+Provenance: the step (`train`), `_recolor`, the loss plumbing and the data sources are original.  The API-compatibility
+shell -- the `recoloringTrainer.__init__` attribute block, `config` / `write_config` / `load_config`, `print_log`,
+`model_name`, `init_folders`, `clear`, `save`, `load` and `evaluate`'s parameter list -- follows the reference method for
+method (ReHistoGAN/rehistoGAN.py:721-893, 1076-1226), because its CLI, checkpoints and scripts address these names;
+none of it is on the timed path.
 """
 import json
 from math import floor, log2, pi

@@ -221,8 +221,8 @@ class HistoGAN(nn.Module):
         for f in (self._flat_g, self._flat_d, self._flat_ema):
             ddp.broadcast_flat(f)
         ddp.broadcast_buffers(self)
-        self._reduce_g = ddp.GradAllReduce(self._flat_g)
-        self._reduce_d = ddp.GradAllReduce(self._flat_d)
+        self._reduce_g = ddp.GradAllReduce(self._flat_g, ddp.BUCKETS)
+        self._reduce_d = ddp.GradAllReduce(self._flat_d, ddp.BUCKETS)
         # packed conv weights are reused between the forward passes of one step (invalidated by the optimizers)
         enable_pack_cache(list(self.G.parameters()) + list(self.D.parameters()) + list(self.GE.parameters()))
 
@@ -643,8 +643,12 @@ class Trainer():
                 alpha, apply_path_penalty, gs, early, g_forward, aug, total_gen_loss, total_hist_loss)
         finally:
             set_requires_grad(Disc, True)
-        GAN._reduce_g()
-        GAN.G_opt.step()
+        if ddp.is_dist():
+            GAN._reduce_g.start()
+            GAN.G_opt.step_buckets(GAN._reduce_g)
+        else:
+            GAN._reduce_g()
+            GAN.G_opt.step()
 
         return torch.stack([total_disc_loss, total_gen_loss, total_hist_loss, gp_val.reshape(()),
                             q_val.reshape(()), pl_len if pl_len is not None else zero()]).double()
@@ -664,8 +668,11 @@ class Trainer():
             else:
                 noise, hist_batch, w_styles, h_w_space, generated_images = g_forward()
             if not d_updated:           # D must be updated before it scores the new fakes (reference order)
-                GAN._reduce_d.finish()
-                GAN.D_opt.step()
+                if ddp.is_dist():       # bucket by bucket: the update of bucket i under the all-reduce of bucket i+1
+                    GAN.D_opt.step_buckets(GAN._reduce_d)
+                else:
+                    GAN._reduce_d.finish()
+                    GAN.D_opt.step()
                 d_updated = True
             fake_output, _ = Disc(aug(generated_images))
             generated_histograms = self.histBlock(generated_images, pre_relu=True)   # == histBlock(F.relu(.)), reference :955

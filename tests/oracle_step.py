@@ -157,4 +157,9 @@ def lrelu_margin(sd_d, images, nblk):
         x = F.leaky_relu(pre, 0.2) + F.conv2d(x, sd[p + 'conv_res.weight'], sd[p + 'conv_res.bias'])
         if p + 'downsample.weight' in sd:
             x = F.conv2d(x, sd[p + 'downsample.weight'], sd[p + 'downsample.bias'], padding=1, stride=2)
+        for j in range(2):          # Residual(Rezero(ImageLinearAttention)) x 2 on attention layers (no LeakyReLU inside)
+            a = f'attn_blocks.{i}.{j}.fn.'
+            if a + 'g' in sd:
+                from oracle import histogan_nets as N
+                x = N.image_linear_attention(sd, a + 'fn.', x) * sd[a + 'g'] + x
     return m

@@ -1,0 +1,88 @@
+"""BASELINE.json configs[4] at reduced width: 1024 x 1024 images, h = 128 inverse-quadratic histogram,
+discriminator attention, batch 1 per GPU -- network_capacity 2 instead of 16 so that the fp64 oracle step fits a test.
+
+One gradient-penalty Trainer.train() step against the oracle step (oracle/histogan_nets.py incl. the restated linear
+attention, parity unpinned as stated there): losses, the penalty, generator-side gradients by the 2x criterion and the
+discriminator's logit-layer gradient.
+
+Why the full-width probe of round 2 (profiles/r02_c5_probe.json) shows D = 6.8e9 / G = 2.6e11: `HistoGAN._init_weights`
+draws EVERY convolution / linear weight kaiming_normal(fan_in) (reference histoGAN/histoGAN.py:686-696), the discriminator
+has no normalisation and sums a residual branch per block, and its last feature map goes through Linear(2*2*filters[-1], 1)
+un-normalised (:611): the logit scale grows with depth and width (measured here: |logit| ~ 3e2 at 256^2 / capacity 16,
+~1e1 at this width, 1e9..1e11 at 1024^2 / capacity 16 with 8192 channels).  The oracle -- the reference's own forward --
+produces the same values: it is the reference's behaviour at initialisation, not a numerical problem of the kernels."""
+import numpy as np
+import pytest
+import torch
+
+from oracle_step import ReplayRng, lrelu_margin, oracle_train_step
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+
+
+def test_c5_reduced_width_step_matches_oracle(gpu_device, tmp_path):
+    from histoGAN import Trainer
+    from oracle import rgbuv_hist as OH
+    torch.manual_seed(41)
+    dev, S_, CAP, HB, B, LAT, ALPHA, LR = gpu_device, 1024, 2, 128, 1, 512, 2.0, 2e-4
+    tr = Trainer('c5', tmp_path / 'r', tmp_path / 'm', S_, CAP, batch_size=B, lr=LR, hist_bin=HB, hist_insz=150,
+                 hist_resizing='interpolation', hist_method='inverse-quadratic', attn_layers=[3, 4], mixed_prob=1.1)
+    tr.graph_mode = '0'
+    tr.run_evaluate = tr.run_save = False
+    tr.init_GAN()
+    GAN = tr.GAN
+    with torch.no_grad():
+        for k, v in GAN.D.named_parameters():
+            if k.endswith('.g'):
+                v.fill_(0.5)                  # Rezero gates start at 0 (attention switched off): open them
+        for blk in GAN.G.blocks:
+            blk.to_noise1.weight.normal_(std=0.3); blk.to_noise2.weight.normal_(std=0.3)
+    L = GAN.G.num_layers
+    assert L == 9 and len(GAN.D.blocks) == 10 and any(k.startswith('attn_blocks.2.') for k in GAN.D.state_dict())
+    sd0 = {k: v.detach().clone() for k, v in GAN.state_dict().items()}
+    sd_d = {k[2:]: v for k, v in sd0.items() if k.startswith('D.')}
+    for data_seed in range(9, 89):       # a real image without a LeakyReLU pre-activation at fp32 rounding distance from zero
+        gen = torch.Generator().manual_seed(data_seed)
+        batches = []
+        for _ in range(2):
+            img = torch.rand(B, 3, S_, S_, generator=gen)
+            hist = OH.rgbuv_hist(torch.rand(B, 3, 256, 256, generator=gen), h=HB)
+            batches.append({'images': img.to(dev), 'histograms': hist.to(dev)})
+        if lrelu_margin(sd_d, batches[0]['images'], len(GAN.D.blocks)) > 5e-8:
+            break
+    tr.loader = iter(batches)
+    tr.rng = ReplayRng(dev, B, L, LAT, S_, 80, tt=3)
+    tr.steps = 4
+    tr.train(alpha=ALPHA)
+    new = {k: v.detach() for k, v in GAN.state_dict().items()}
+    d_used = {k[2:]: v for k, v in new.items() if k.startswith('D.')}
+    truth = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, 80, tt=3, dtype=torch.float64), L, HB, ALPHA, LR,
+                              True, False, d_override=d_used)
+    ref32 = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, 80, tt=3), L, HB, ALPHA, LR, True, False,
+                              d_override=d_used)
+    rel = lambda a, b: abs(a - b) / max(1.0, abs(b))
+    assert all(np.isfinite(v) for v in (tr.d_loss, tr.g_loss, tr.h_loss, tr.last_gp_loss))
+    assert rel(tr.d_loss, truth['d_loss']) <= 1e-4 and rel(tr.g_loss, truth['g_loss']) <= 1e-4
+    assert abs(tr.h_loss - truth['h_loss']) <= 1e-4 and rel(tr.last_gp_loss, truth['gp']) <= 1e-4
+    # generator side (through the h = 128 histogram on 1024^2 -> 150^2 and the attention discriminator): 2x criterion
+    gk = [pk for pk in truth['grads'] if pk[0] != 'D']
+    tn = torch.cat([truth['grads'][pk].flatten() for pk in gk]).norm()
+    mine = {pk: dict(getattr(GAN, pk[0]).named_parameters())[pk[1]].grad.detach().double() for pk in gk}
+    d_o = float(torch.cat([(mine[pk] - truth['grads'][pk]).flatten() for pk in gk]).norm() / tn)
+    d_r = float(torch.cat([(ref32['grads'][pk].double() - truth['grads'][pk]).flatten() for pk in gk]).norm() / tn)
+    assert d_o <= 2 * d_r + 1e-6, (d_o, d_r)
+    # discriminator: the attention projections' and the logit layer's gradients of the penalty step (a LeakyReLU mask flip
+    # of an fp32 evaluation -- see oracle_step.lrelu_margin -- would show as ~1e-2; the bar leaves room for none)
+    off, grads = 0, {}
+    for prm in GAN._flat_d.params:
+        n = prm.numel()
+        grads[next(k for k, v in GAN.D.named_parameters() if v is prm)] = GAN._flat_d.grad[off:off + n].view(prm.shape)
+        off += n
+    for name in ('to_logit.weight', 'attn_blocks.2.0.fn.fn.to_q.weight', 'attn_blocks.3.1.fn.fn.to_out.weight', 'blocks.9.net.0.weight'):
+        e_o, e_r = _rel(grads[name], truth['grads'][('D', name)]), _rel(ref32['grads'][('D', name)], truth['grads'][('D', name)])
+        assert e_o <= max(2e-4, 3 * e_r), (name, e_o, e_r)

@@ -407,3 +407,26 @@ def test_generator_block_forward_explicit_noise(up, gpu_device):
     assert relmax(xa.detach().cpu().numpy(), ref.cpu().numpy()) <= 1e-5
     with pytest.raises(Exception, match='No noise is given'):
         blk.forward_(x, prev, s1, s2, srgb)
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 4, 4), (3, 7, 16, 16), (2, 3, 2, 2), (1, 2, 64, 64), (2, 3, 5, 7), (1, 1, 3, 1)])
+def test_upsample_adjoint_paths_agree(shape, gpu_device):
+    """hg_modulate_bwd with upsample: the two-pixels-per-thread kernel (even widths, 16-byte-aligned rows: vector loads +
+    wave shuffles) and the general one-pixel-per-thread kernel (odd widths, unaligned views) compute the same gx bit for
+    bit (same fma order) and both match torch's adjoint of F.interpolate(scale_factor=2, bilinear)."""
+    from histogan_amd import ops
+    torch.manual_seed(8)
+    B, C, H, W = shape
+    x = torch.randn(B, C, H, W, device=gpu_device, requires_grad=True)
+    s = torch.randn(B, C, device=gpu_device, requires_grad=True)
+    go = torch.randn(B, C, 2 * H, 2 * W, device=gpu_device)
+    gx, gs = torch.autograd.grad(ops.modulate(x, s, True), (x, s), go)
+    ref = F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) * (s + 1)[:, :, None, None]
+    rx, rs = torch.autograd.grad(ref, (x, s), go)
+    assert relmax(gx.cpu().numpy(), rx.cpu().numpy()) <= 1e-5 and relmax(gs.cpu().numpy(), rs.cpu().numpy()) <= 1e-5
+    # the same call on a view whose storage is off by one float: the general kernel
+    buf = torch.empty(go.numel() + 1, device=gpu_device)
+    go2 = buf[1:].view_as(go).copy_(go)
+    assert go2.data_ptr() % 16 != 0
+    gx2, gs2 = torch.autograd.grad(ops.modulate(x, s, True), (x, s), go2)
+    assert torch.equal(gx2, gx) and relmax(gs2.cpu().numpy(), gs.cpu().numpy()) <= 1e-6

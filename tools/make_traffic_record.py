@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""profiles/r03_pmc_traffic.json from the traffic.txt files of tools/conv_traffic.sh (roofline conv + wgrad + dense
+histogram kernels) and tools/hist_traffic.sh with HG_HIST_METHOD=thresholding: FETCH_SIZE / WRITE_SIZE (KB, separate
+passes) per launch, with the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md for 16-byte-per-lane streams
+(FETCH_SIZE reports half), stamped with the digest of the kernel source they were measured on -- bench.py reports
+`traffic` only while that digest still matches.
+
+    python tools/make_traffic_record.py <conv traffic.txt> <thr traffic.txt> <commit>"""
+import hashlib
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse(path):
+    out, cur = {}, None
+    for line in open(path):
+        m = re.match(r'## (.*)', line)
+        if m:
+            cur = m.group(1)
+            out[cur] = {}
+            continue
+        m = re.match(r'\s+(\w+)\s+([\d.]+)\s+\(n=', line)
+        if m and cur:
+            out[cur][m.group(1)] = float(m.group(2))
+        m = re.match(r'\s+duration_us\(avg under PMC\) = ([\d.]+)', line)
+        if m and cur:
+            out[cur]['duration_us'] = float(m.group(1))
+    return out
+
+
+def digest(name):
+    with open(os.path.join(ROOT, 'histogan_amd', 'csrc', name), 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def find(d, sub):
+    for k, v in d.items():
+        if sub in k:
+            return k, v
+    return None, None
+
+
+conv, thr, commit = parse(sys.argv[1]), parse(sys.argv[2]), sys.argv[3]
+bench = {}
+k, v = find(conv, 'k_conv<')
+bench['k_conv_fwd_256_128_64_b32'] = dict(fetch_bytes=v['FETCH_SIZE'] * 1024, write_bytes=v['WRITE_SIZE'] * 1024, kernel=k[:90],
+                                          comment='4-byte-per-lane halo loads: FETCH_SIZE as reported', source='hg_conv.hip',
+                                          source_sha16=digest('hg_conv.hip'), commit=commit)
+k, v = find(conv, 'k_wgrad<')
+bench['k_wgrad_256_128_64_b32'] = dict(fetch_bytes=v['FETCH_SIZE'] * 1024, write_bytes=v['WRITE_SIZE'] * 1024, kernel=k[:90],
+                                       source='hg_conv.hip', source_sha16=digest('hg_conv.hip'), commit=commit)
+k, v = find(conv, 'k_hist_bwd<')
+bench['k_hist_bwd_c2'] = dict(fetch_bytes=2 * v['FETCH_SIZE'] * 1024, write_bytes=v['WRITE_SIZE'] * 1024, fetch_kb_reported=v['FETCH_SIZE'],
+                              comment='16-byte-per-lane streams (projection cache, x): reported FETCH_SIZE x 2 (gfx950 correction)',
+                              source='hg_hist.hip', source_sha16=digest('hg_hist.hip'), commit=commit)
+k, v = find(conv, 'k_hist_fwd<')
+bench['k_hist_fwd_c2'] = dict(fetch_bytes=v['FETCH_SIZE'] * 1024, write_bytes=v['WRITE_SIZE'] * 1024, source='hg_hist.hip',
+                              source_sha16=digest('hg_hist.hip'), commit=commit)
+t = {}
+tot = 0.0
+for name in ('k_thr_fwd_lean', 'k_hist_finish', 'k_thr_bwd_lean'):
+    k, v = find(thr, name)
+    if v:
+        t[name] = dict(fetch_kb_reported=v['FETCH_SIZE'], fetch_bytes_corrected=2 * v['FETCH_SIZE'] * 1024, write_bytes=v['WRITE_SIZE'] * 1024,
+                       duration_us_under_pmc=v.get('duration_us'))
+        tot += 2 * v['FETCH_SIZE'] * 1024 + v['WRITE_SIZE'] * 1024
+t['total_fabric_bytes_fwd_bwd'] = tot
+t['algorithmic_bytes_fwd_bwd'] = 78643200
+rec = dict(_note='rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), per launch, counter unit KB; FETCH_SIZE '
+                 'doubled for 16-byte-per-lane streams per /opt/skills/guides/MI355X_MICROARCH.md (HBM section); Infinity-Cache hits '
+                 'are counted (fabric traffic: an upper bound on HBM traffic)', thresholding_b32_256x256_h64=t, bench=bench)
+with open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'), 'w') as f:
+    json.dump(rec, f, indent=1)
+print(json.dumps(rec, indent=1)[:1200])
