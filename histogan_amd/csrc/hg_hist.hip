@@ -548,6 +548,9 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
     // Kernel values are generated just in time (3 evaluations per 6*T MFMAs) and NOT kept: the
     // epilogue re-evaluates them bit-identically, which keeps the kernel at W (48*T regs) + temporaries
     // so that several waves per SIMD can overlap one wave's VALU phases with another's MFMAs.
+    // (Round 3 also ran this loop in groups of four steps -- within a group beta0 advances by one, so the twelve LDS operand
+    // addresses and the bin offset become immediates: 24 -> 16.75 VALU instructions per 12 MFMAs in the ISA -- and measured
+    // 0.9515 vs 0.955 ms at configs[1]: the K loop is not VALU-issue-bound.  The one-step form stays.)
     // MFMA loop: a REAL loop over the 16*T K-steps (2 bins each).  Fully unrolled, the compiler hoists
     // the (round-invariant) LDS operand reads and sinks the chain-free MFMA intrinsics below them,
     // which costs >200 spilled VGPRs; one 6*T-MFMA body (384*T cycles) per iteration needs no unroll.
