@@ -25,6 +25,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: what RCCL / cross-process device memory need on these hosts
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -433,7 +435,7 @@ def main():
     dist = None
     if world > 1 or os.environ.get('HG_DIST_FORCE', '0') == '1':    # (forced at world size 1: RCCL exercised on one GPU)
         import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # 'nccl' == RCCL over xGMI.  HG_DIST_BACKEND=gloo exists to exercise the N>1 path on a box with fewer GPUs than
         # ranks (ranks then share a device; test use only)
         backend = os.environ.get('HG_DIST_BACKEND', 'nccl')
