@@ -380,7 +380,9 @@ def register_grad_slots(flat):
 def side_stream(device):
     st = _side_streams.get(device.index)
     if st is None:
-        st = _side_streams[device.index] = torch.cuda.Stream(device=device)
+        # HG_W_STREAM_PRIO: HIP priority of the weight-gradient stream (0 normal, -1 high), an experiment knob
+        st = _side_streams[device.index] = torch.cuda.Stream(
+            device=device, priority=int(__import__('os').environ.get('HG_W_STREAM_PRIO', '0')))
     return st
 
 

@@ -452,10 +452,17 @@ __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvAr
 struct ConvArgs4 {
   ConvArgs c[4];
   int tiles[4];    // pixel tiles (grid x extent) of each class
+  int xcd_map;     // block id -> (tile, class) mapping, see k_conv_parity4
 };
+// Block -> (tile, class): workgroups go to the 8 XCDs round robin by linear id, and the two classes of one row parity
+// write the even / odd floats of the same cache lines.  With id = 32 q + 8 c + x the four classes of tile 8 q + x run on
+// XCD x within 32 ids of each other, so the half-written lines of one class meet the other half in that XCD's L2 and
+// leave it as whole lines (the classes on different XCDs -- or in separate launches -- send masked partial lines to
+// memory: 1.6 TB/s on the 256^2 maps of the first discriminator block, 2.26 TB/s paired; tools/s2_dgrad_probe.py).
 template <int WC, int WP, int TC, int TP, int KC, bool SM, int MT, bool FE>
 __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv_parity4(const ConvArgs4 a) {
-  const int cls = blockIdx.x & 3, t = blockIdx.x >> 2;
+  const int cls = a.xcd_map ? (blockIdx.x >> 3) & 3 : blockIdx.x & 3;
+  const int t = a.xcd_map ? (blockIdx.x >> 5) * 8 + (blockIdx.x & 7) : blockIdx.x >> 2;
   if (t >= a.tiles[cls]) return;
   if (cls == 0) conv_body<WC, WP, TC, TP, 1, KC, 1, SM, MT, FE>(a.c[0], t, blockIdx.y, blockIdx.z);
   else if (cls == 1) conv_body<WC, WP, TC, TP, 2, KC, 1, SM, MT, FE>(a.c[1], t, blockIdx.y, blockIdx.z);
@@ -1225,7 +1232,7 @@ int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t
 }
 
 // the four parity-class launches of a stride-2 data gradient as one (k_conv_parity4); the caller reduces the K-split slabs
-template <int WC, int WP, int TC, int TP, int KC, bool SM = false, int MT = 32>
+template <int WC, int WP, int TC, int TP, int KC, bool SM = false, int MT = 32, bool WITH_FE = true>
 int launch_conv_parity4(const ConvArgs (&base)[4], const Taps (&tp)[4], int ksplit, hipStream_t st) {
   constexpr int NB = WC * TC * MT, NT = WC * WP * 64;
   ConvArgs4 a4;
@@ -1248,11 +1255,18 @@ int launch_conv_parity4(const ConvArgs (&base)[4], const Taps (&tp)[4], int kspl
   if (!tiles_max) return HG_OK;
   const ConvArgs &a = base[0];
   const bool fe = a.iscale || a.oscale || a.noise_img || a.slope > 0.f;
-  auto kern = fe ? k_conv_parity4<WC, WP, TC, TP, KC, SM, MT, true> : k_conv_parity4<WC, WP, TC, TP, KC, SM, MT, false>;
+  if (fe && !WITH_FE) return HG_EUNSUPPORTED;
+  auto kern = k_conv_parity4<WC, WP, TC, TP, KC, SM, MT, false>;
+  if constexpr (WITH_FE) { if (fe) kern = k_conv_parity4<WC, WP, TC, TP, KC, SM, MT, true>; }
   static int state[2][2] = {{0, 0}, {0, 0}};
   const int ny = (a.N + NB - 1) / NB;
   if (int rc = fit_blocks_per_cu((const void *)kern, NT, tiles_sum * ny * ksplit, lds, state[fe], "k_conv_parity4")) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(4 * tiles_max), (unsigned)ny, (unsigned)ksplit), dim3(NT), lds, st, a4);
+  // (only where the tiles alone cover the XCDs: 4 tiles x 16 channel blocks of a 4x4 map would use 4 of the 8 -- 94 -> 163 us)
+  static const bool xcd_env = !(getenv("HG_PARITY_XCD") && atoi(getenv("HG_PARITY_XCD")) == 0);
+  const bool xcd_map = xcd_env && tiles_max >= 64;
+  a4.xcd_map = xcd_map;
+  const unsigned gx = xcd_map ? (unsigned)((tiles_max + 7) / 8 * 32) : (unsigned)(4 * tiles_max);
+  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)ny, (unsigned)ksplit), dim3(NT), lds, st, a4);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
@@ -1650,7 +1664,20 @@ int hg_conv2d_dgrad(const float *gout, const float *wt, float *gin, const float 
             ++t.n;
           }
     }
-  static const bool merge4 = !(getenv("HG_DGRAD_S2_MERGE") && atoi(getenv("HG_DGRAD_S2_MERGE")) == 0);
+  static const int merge4 = getenv("HG_DGRAD_S2_MERGE") ? atoi(getenv("HG_DGRAD_S2_MERGE")) : 2;
+  if (merge4 >= 2 && !plan64 && Hi > 1 && Wi > 1) {
+    // large maps: the four classes in one launch as well, for the cache-line pairing of k_conv_parity4's block order
+    const ConvPlan p = plan_conv(B, K, N, Hi / 2, Wi / 2, 1, 2, false, false, 4);   // (the smallest class)
+    int rc = HG_EUNSUPPORTED;
+    switch (p.tile) {
+      case TILE_16x256: rc = launch_conv_parity4<1, 4, 1, 4, 4, false, 16, false>(ca, tps, 1, st); break;
+      case TILE_32x256: rc = launch_conv_parity4<1, 4, 1, 2, HG_CONV_KC, false, 32, false>(ca, tps, 1, st); break;
+      case TILE_64x256: rc = launch_conv_parity4<1, 4, 2, 2, HG_CONV_KC, false, 32, false>(ca, tps, 1, st); break;
+      case TILE_128x128: rc = launch_conv_parity4<2, 2, 2, 2, HG_CONV_KC, false, 32, false>(ca, tps, 1, st); break;
+      default: break;
+    }
+    if (rc != HG_EUNSUPPORTED) return rc;
+  }
   if (merge4 && plan64) {
     // small maps (the 64x64 tile): the four classes in one launch
     // (one launch has the blocks of all four classes: half the K split planned per class fills the chip as well, with

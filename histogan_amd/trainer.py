@@ -50,13 +50,18 @@ from .optim import DiffGrad, FlatParams, ema_update
 EPS = 1e-8
 EXTS = ['jpg', 'png']
 G_OVERLAP = os.environ.get('HG_G_OVERLAP', '1') != '0'   # G-phase generator forward on a second stream beside the D phase
+G_STREAM_PRIO = int(os.environ.get('HG_G_STREAM_PRIO', '0'))   # HIP priority of that stream (0 normal, -1 high)
+D_STEP_EARLY = os.environ.get('HG_D_STEP_EARLY', '1') != '0'   # D's optimizer step before main waits for that stream
 # Plain steps replayed from a captured hipGraph (single process): HG_GRAPH = auto (default) | 1 | 0 | 2.
-#   auto: decided from the first eager plain steps -- the graph is used when the host's enqueue work is the larger part
-#         of the step (small batches, slow hosts: batch 4 at 256^2 runs 30 -> 20 ms); a GPU-bound step stays eager, where
-#         the side-stream overlaps (conv.py, `_g_stream`) are worth 2-3 % that a replayed multi-branch graph does not keep.
+#   auto: decided from the first eager plain steps -- the graph is used when the host's enqueue work IS the step (small
+#         batches, slow hosts: batch 4 at 256^2 runs 30 -> 20 ms; the enqueue time then equals the GPU-side step time,
+#         ratio ~1); a GPU-bound step stays eager, where the side-stream overlaps (conv.py, `_g_stream`) are worth 2-4 %
+#         that a replayed multi-branch graph does not keep (C3: 48.3 eager vs 50.1 ms replayed at a ratio of 0.5).  The
+#         smallest ratio seen decides: the first steps of a process enqueue slowly (allocator growth, cold caches) and
+#         say nothing about the steady state.
 #   2:    the static-input step WITHOUT capture (A/B of the replay: identical parameter checksums, tools/graph_probe.py)
 GRAPH_MODE = os.environ.get('HG_GRAPH', 'auto')
-GRAPH_AUTO_RATIO = float(os.environ.get('HG_GRAPH_AUTO_RATIO', '0.6'))
+GRAPH_AUTO_RATIO = float(os.environ.get('HG_GRAPH_AUTO_RATIO', '0.9'))
 GRAPH_GP = os.environ.get('HG_GRAPH_GP', '1') != '0'      # gradient-penalty steps replay from their own graph too
 LAZY_STATS = os.environ.get('HG_LAZY_STATS', '1') != '0'  # statistics of step n read while step n+1 is queued (0: blocking read-back every step)
 
@@ -388,7 +393,7 @@ class Trainer():
     # ------------------------------------------------------------------------------------------
     def _g_stream(self):
         if getattr(self, '_gstream', None) is None:
-            self._gstream = torch.cuda.Stream(device=self.device)
+            self._gstream = torch.cuda.Stream(device=self.device, priority=G_STREAM_PRIO)
         return self._gstream
 
     def _w_and_hw(self, style, hist_batch):
@@ -419,10 +424,10 @@ class Trainer():
         if self.graph_mode == 'auto':
             use = getattr(self, '_graph_auto', None)
             if use is None:
-                r = sorted(getattr(self, '_host_ratio', []))
+                r = getattr(self, '_host_ratio', [])
                 if len(r) < 2:
                     return False
-                use = self._graph_auto = r[len(r) // 2] > GRAPH_AUTO_RATIO
+                use = self._graph_auto = min(r) > GRAPH_AUTO_RATIO
             return use
         return True
 
@@ -658,6 +663,18 @@ class Trainer():
         GAN, dev, Disc, acc = self.GAN, self.device, self.GAN.D, self.gradient_accumulate_every
         pl_len = None
         d_updated = False
+        def update_d():         # D must be updated before it scores the new fakes (reference order)
+            if ddp.is_dist():   # bucket by bucket: the update of bucket i under the all-reduce of bucket i+1
+                GAN.D_opt.step_buckets(GAN._reduce_d)
+            else:
+                GAN._reduce_d.finish()
+                GAN.D_opt.step()
+
+        if early is not None and D_STEP_EARLY:
+            # the update only needs D's gradients: enqueued before this stream waits for the second one, it runs under
+            # the tail of the G-phase generator forward when that is still in flight
+            update_d()
+            d_updated = True
         for i in range(acc):
             if early is not None:
                 torch.cuda.current_stream(dev).wait_stream(self._g_stream())
@@ -667,12 +684,8 @@ class Trainer():
                 early = None
             else:
                 noise, hist_batch, w_styles, h_w_space, generated_images = g_forward()
-            if not d_updated:           # D must be updated before it scores the new fakes (reference order)
-                if ddp.is_dist():       # bucket by bucket: the update of bucket i under the all-reduce of bucket i+1
-                    GAN.D_opt.step_buckets(GAN._reduce_d)
-                else:
-                    GAN._reduce_d.finish()
-                    GAN.D_opt.step()
+            if not d_updated:
+                update_d()
                 d_updated = True
             fake_output, _ = Disc(aug(generated_images))
             generated_histograms = self.histBlock(generated_images, pre_relu=True)   # == histBlock(F.relu(.)), reference :955
