@@ -11,10 +11,11 @@ tmp = tempfile.mkdtemp()
 tr = Trainer('c5', tmp+'/r', tmp+'/m', 1024, 16, batch_size=8, hist_bin=128, hist_insz=150, attn_layers=ATTN)
 tr.run_evaluate = tr.run_save = False
 tr.set_synthetic_data_src(pool=2)
-for _ in range(3): tr.train()
+for _ in range(10): tr.train()      # incl. the HG_GRAPH=auto decision (and the captures, if it takes the graph)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 n = 8
 for _ in range(n): tr.train()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print(json.dumps(dict(workload='HistoGAN 1024^2 cap16 B=8 h=128 attn_layers=%s train step' % ATTN, ms_per_step=round(dt*1e3, 1), images_per_s=round(8/dt, 2),
-      mem_gb=round(torch.cuda.max_memory_allocated()/2**30, 1), d=tr.d_loss, g=tr.g_loss)))
+      mem_gb=round(torch.cuda.max_memory_allocated()/2**30, 1), d=tr.d_loss, g=tr.g_loss,
+      graph_replay=bool(getattr(tr, '_graph_auto', False)), host_ratio=[round(v, 3) for v in getattr(tr, '_host_ratio', [])])))
