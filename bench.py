@@ -410,7 +410,18 @@ def ddp_probe(dist, dev, rank, world, tr):
     return info
 
 
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  librccl writes a version banner to the C stdout when the process group is
+    torn down (5 lines behind the JSON at any world size), and a stray library print would do the same: file descriptor 1
+    is pointed at stderr for everything in this process, and the JSON line goes to the original stdout."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(saved, 'w')
+
+
 def main():
+    json_out = claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=32)
@@ -526,7 +537,8 @@ def main():
         if rank == 0:
             print(json.dumps({'metric': METRIC, 'value': units * world * args.steps / dt, 'unit': 'images/s', 'n_gpus': world,
                               'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
-                              'config': info, 'ddp': ddp_info, 'roofline': None}), flush=True)
+                              'config': info, 'ddp': ddp_info, 'roofline': None,
+                              'graph_replayed_steps': int(sum(graphed))}), file=json_out, flush=True)
         if dist:
             dist.destroy_process_group()
         return
@@ -608,7 +620,7 @@ def main():
                 out['cpu_baseline'] = cpu_baseline_train(args) if args.workload == 'train' else cpu_baseline(args)
             if args.workload == 'train' and not args.no_reference_eager:
                 out['reference_eager_rocm'] = reference_eager_rocm(args, dev)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
     if dist:
         dist.destroy_process_group()
 

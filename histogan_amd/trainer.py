@@ -28,6 +28,7 @@ address exactly these names; none of it is on the timed path.
 """
 import json
 import os
+import sys
 from math import floor, log2
 from pathlib import Path
 from random import random
@@ -428,6 +429,10 @@ class Trainer():
                 if len(r) < 2:
                     return False
                 use = self._graph_auto = min(r) > GRAPH_AUTO_RATIO
+                if self.is_main:
+                    print(f'train step: HG_GRAPH=auto -> {"hipGraph replay" if use else "eager"} (host enqueue / GPU step '
+                          f'time of the first plain steps: {", ".join(f"{v:.2f}" for v in r)}; threshold {GRAPH_AUTO_RATIO})',
+                          file=sys.stderr)
             return use
         return True
 
@@ -502,7 +507,7 @@ class Trainer():
                     o.step_count -= 1
                 self._graph_failed = True
                 torch.cuda.synchronize()
-                print(f'hipGraph capture of the train step failed ({type(e).__name__}: {e}); running eagerly')
+                print(f'hipGraph capture of the train step failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr)
                 self._reset_after_failed_step()
                 return self._device_step(alpha, gp, False, None)
             for o in (GAN.D_opt, GAN.G_opt):
@@ -512,7 +517,7 @@ class Trainer():
             if not getattr(self, '_graph_logged', False) and self.is_main:
                 self._graph_logged = True
                 print(f'train step: replaying captured hipGraphs (HG_GRAPH={self.graph_mode}; latent / noise draws follow '
-                      f'the static-input order -- for seed-reproducible runs pin HG_GRAPH=0 or 1)')
+                      f'the static-input order -- for seed-reproducible runs pin HG_GRAPH=0 or 1)', file=sys.stderr)
         graph, stats = graphs[key]
         graph.replay()
         weights_changed()                      # eager steps in between must not trust operands packed by the graph

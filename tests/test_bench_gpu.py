@@ -24,8 +24,9 @@ def _bench(extra_env, *args):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), *args], env=env, cwd=ROOT, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
-    return json.loads(line)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith('{'), lines      # the contract: ONE JSON line on stdout, diagnostics on stderr
+    return json.loads(lines[0])
 
 
 def test_bench_train_on_rccl_world1(gpu_device):
@@ -45,3 +46,11 @@ def test_bench_hist_line_has_the_contract_fields(gpu_device):
     assert out['roofline']['bound'] == 'mfma' and 0 < out['roofline']['frac'] < 1
     assert out['cpu_baseline']['kind'] == 'port' and out['cpu_baseline']['cpu']
     assert out['roofline']['thresholding']['bound'] == 'hbm'
+
+
+def test_bench_train_stdout_is_one_json_line_under_graph_replay(gpu_device):
+    """Round 3: the 'replaying captured hipGraphs' note went to stdout, a second line in front of the JSON whenever
+    HG_GRAPH=auto (or 1) took the graph."""
+    out = _bench({'HG_GRAPH': '1'}, '--gpus', '1', '--steps', '12', '--warmup', '2', '--batch', '4', '--no-roofline',
+                 '--no-cpu-baseline', '--no-reference-eager')
+    assert out['graph_replayed_steps'] > 0 and out['value'] > 0
