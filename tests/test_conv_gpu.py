@@ -34,7 +34,10 @@ CASES = [
 
 # stride-2 cases (3x3): the discriminator's down-sampling convolution (histoGAN/histoGAN.py:517-518)
 CASES_S2 = [(2, 16, 16, 64, 64), (2, 16, 16, 32, 32), (3, 5, 7, 9, 13), (2, 64, 64, 16, 16), (4, 70, 130, 8, 8), (2, 32, 32, 64, 64),
-            (1, 3, 4, 5, 4), (8, 128, 128, 4, 4), (2, 16, 16, 128, 128), (5, 33, 65, 2, 2), (1, 2, 2, 1, 1)]
+            (1, 3, 4, 5, 4), (8, 128, 128, 4, 4), (2, 16, 16, 128, 128), (5, 33, 65, 2, 2), (1, 2, 2, 1, 1),
+            # >= 64 pixel tiles per parity class: the data gradient's one-launch form with the XCD-paired block order, odd
+            # sizes (the four classes differ by a row / column), each of the large-map tile shapes (16 / 32 / 64 / 128 channels)
+            (8, 16, 16, 255, 257), (6, 24, 32, 127, 130), (12, 48, 64, 97, 61), (20, 96, 128, 63, 65)]
 
 
 @pytest.mark.parametrize('B,K,N,H,W', CASES_S2)
