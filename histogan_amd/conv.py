@@ -360,6 +360,7 @@ def conv_wgrad(x, gout, ksize, stride=1, iscale=None, gscale=None, out=None):
 # FlatParams.gather() makes the main stream wait for the side stream before anything reads the buffer.
 SIDE_WGRAD = os.environ.get('HG_WGRAD_STREAM', '1') != '0'
 GRAPH_WGRAD_INLINE = os.environ.get('HG_GRAPH_WGRAD_INLINE', '1') != '0'
+DIRECT_DEMOD = os.environ.get('HG_DIRECT_DEMOD', '1') != '0'   # demodulation's weight-gradient term into the flat slot (direct_weight_term)
 _slots = {}          # (data_ptr, shape) of a registered weight -> (offset, numel, weakref to the owner FlatParams)
 _side_streams = {}   # device index -> torch.cuda.Stream
 
@@ -427,6 +428,45 @@ def _direct_wgrad(w, x, g, stride):
             flat.direct_written.add(skey)
     xc.record_stream(side)                           # the caching allocator must not recycle them under the kernel
     gc.record_stream(side)
+    return True
+
+
+def direct_weight_term(w, M, scale):
+    """slot(w) += scale * w * M[:, :, None, None] -- a weight-gradient term that is not a convolution's (the demodulation
+    coefficient's, ops._DemodCoeff) added straight to w's flat-buffer slot on the weight-gradient stream, in one pass
+    (read w, read / write the slot) instead of two element-wise launches, a gradient tensor for autograd and the
+    `both` add of FlatParams.gather (7 passes over the generator's 78 M convolution weights per step).  False: no slot
+    (or a higher-order pass / a recording graph) -- the caller returns the term to autograd."""
+    if not (SIDE_WGRAD and DIRECT_DEMOD) or torch.is_grad_enabled():
+        return False
+    key = (w.data_ptr(), tuple(w.shape))
+    ent = _slots.get(key)
+    if ent is None:
+        return False
+    off, n, ref = ent
+    flat = ref()
+    if flat is None or not getattr(flat, 'direct_ok', False):
+        return False
+    slot = flat.grad[off:off + n].view(w.shape)
+    skey = slot.data_ptr()
+    Mb = M[:, :, None, None]
+
+    def run():
+        if skey in flat.direct_written:
+            slot.addcmul_(w, Mb, value=scale)
+        else:
+            torch.mul(w, Mb * scale, out=slot)
+            flat.direct_written.add(skey)
+
+    if GRAPH_WGRAD_INLINE and torch.cuda.is_current_stream_capturing():
+        run()
+        return True
+    main = torch.cuda.current_stream(w.device)
+    side = side_stream(w.device)
+    side.wait_event(main.record_event())
+    with torch.cuda.stream(side):
+        run()
+    M.record_stream(side)
     return True
 
 

@@ -137,8 +137,10 @@ class GeneratorBlock(nn.Module):
         if self._fused() and conv.stride == 1 and conv.dilation == 1 and conv.kernel in (1, 3):
             return ops.modconv_stage(x, style, conv.weight, nzt, to_noise.weight, to_noise.bias,
                                      demod=conv.demod, upsample=upsample, act=True)
-        c = conv.contract(x, style, upsample)
+        # (d before the convolution: the backward then reaches the convolution's weight gradient first, which writes the flat
+        # gradient slot outright, and the demodulation's weight term accumulates into it -- conv.direct_weight_term)
         d = conv.demod_coeff(style) if conv.demod else None
+        c = conv.contract(x, style, upsample)
         return ops.demod_noise_lrelu(c, d, nzt, to_noise.weight, to_noise.bias)
 
     def forward(self, x, prev_rgb, istyle, inoise, latent=None):

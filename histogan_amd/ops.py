@@ -264,7 +264,10 @@ class _DemodCoeff(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gy = 2.0 * s1 * torch.mm(gq, wsq)
         if ctx.needs_input_grad[1]:
-            gw = 2.0 * w * torch.mm(gq.t(), s1 * s1)[:, :, None, None]
+            from . import conv as C
+            M = torch.mm(gq.t(), s1 * s1)
+            if not C.direct_weight_term(w, M, 2.0):     # training: added to the flat gradient slot on the side stream
+                gw = 2.0 * w * M[:, :, None, None]
         return gy, gw
 
 

@@ -35,7 +35,8 @@ res = {str(v): [] for v in vals}
 for r in range(a.rounds):
     for v in vals:
         if a.toggle:
-            setattr(T, a.toggle, v)
+            mod, _, attr = a.toggle.rpartition(':')          # 'D_STEP_EARLY' (trainer) or 'histogan_amd.conv:DIRECT_DEMOD'
+            setattr(__import__(mod, fromlist=['x']) if mod else T, attr, v)
         for _ in range(2):
             tr.steps = a.index
             tr.train()
