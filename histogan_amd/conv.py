@@ -431,11 +431,11 @@ def _direct_wgrad(w, x, g, stride):
     return True
 
 
-def direct_weight_term(w, M, scale):
-    """slot(w) += scale * w * M[:, :, None, None] -- a weight-gradient term that is not a convolution's (the demodulation
-    coefficient's, ops._DemodCoeff) added straight to w's flat-buffer slot on the weight-gradient stream, in one pass
-    (read w, read / write the slot) instead of two element-wise launches, a gradient tensor for autograd and the
-    `both` add of FlatParams.gather (7 passes over the generator's 78 M convolution weights per step).  False: no slot
+def direct_demod_weight_term(w, gd, d, s1):
+    """The demodulation coefficient's weight-gradient term (ops._DemodCoeff) added straight to w's flat-buffer slot on
+    the weight-gradient stream by one kernel (hg_demod_weight_term: read w, read / write the slot) -- instead of a
+    (N x B) @ (B x K) rocBLAS GEMM (314 us at 2048 x 2048: no library kernel for a 32-deep reduction), two element-wise
+    launches over the weight, a gradient tensor for autograd and the `both` add of FlatParams.gather.  False: no slot
     (or a higher-order pass / a recording graph) -- the caller returns the term to autograd."""
     if not (SIDE_WGRAD and DIRECT_DEMOD) or torch.is_grad_enabled():
         return False
@@ -449,14 +449,16 @@ def direct_weight_term(w, M, scale):
         return False
     slot = flat.grad[off:off + n].view(w.shape)
     skey = slot.data_ptr()
-    Mb = M[:, :, None, None]
+    gd, d, s1 = _f32c(gd), _f32c(d), _f32c(s1)
+    B, N = d.shape
+    K, taps = w.shape[1], w.shape[2] * w.shape[3]
 
     def run():
-        if skey in flat.direct_written:
-            slot.addcmul_(w, Mb, value=scale)
-        else:
-            torch.mul(w, Mb * scale, out=slot)
-            flat.direct_written.add(skey)
+        with on_device(w.device):
+            check(lib.hg_demod_weight_term(w.data_ptr(), gd.data_ptr(), d.data_ptr(), s1.data_ptr(), slot.data_ptr(), B, N, K,
+                                           taps, int(skey in flat.direct_written), raw_stream(w.device)),
+                  'hg_demod_weight_term')
+        flat.direct_written.add(skey)
 
     if GRAPH_WGRAD_INLINE and torch.cuda.is_current_stream_capturing():
         run()
@@ -466,7 +468,8 @@ def direct_weight_term(w, M, scale):
     side.wait_event(main.record_event())
     with torch.cuda.stream(side):
         run()
-    M.record_stream(side)
+    for t in (gd, d, s1):
+        t.record_stream(side)
     return True
 
 

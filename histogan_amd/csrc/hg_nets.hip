@@ -443,6 +443,53 @@ inline unsigned grid_for(long long n_threads) {
   return (unsigned)b;
 }
 
+// Demodulation backward, weight side.  d[b,o] = rsqrt(sum_{i,t} (w[o,i,t] (s[b,i]+1))^2 + eps)  (Conv2DMod,
+// histoGAN/histoGAN.py:427-429, on the shared weight), gd = dL/dd:
+//   gw[o,i,t] (+)= 2 w[o,i,t] M[o,i],   M[o,i] = sum_b gq[b,o] s1[b,i]^2,   gq = gd * (-0.5) * d^3,   s1 = s + 1
+// One block per output channel o: gq's column and M's row in LDS (B-deep dot products, style read coalesced), then one
+// coalesced pass over the K*T weights of that channel.  (As aten ops this was a 2048x32x2048 rocBLAS GEMM -- 314 us, the
+// library has no kernel for a 32-deep reduction -- plus two element-wise passes over the weight and the gradient add.)
+__global__ __launch_bounds__(256) void k_demod_weight_term(const float *__restrict__ w, const float *__restrict__ gd,
+                                                           const float *__restrict__ d, const float *__restrict__ s1,
+                                                           float *__restrict__ gw, int B, int N, int K, int T,
+                                                           int accumulate) {
+  extern __shared__ float dsm[];
+  float *Mrow = dsm, *gqc = dsm + K;
+  const int o = blockIdx.x;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float dd = d[(size_t)b * N + o];
+    gqc[b] = gd[(size_t)b * N + o] * (-0.5f) * dd * dd * dd;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < K; i += 256) {
+    float m = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float sv = s1[(size_t)b * K + i];
+      m = fmaf(gqc[b], sv * sv, m);
+    }
+    Mrow[i] = 2.f * m;
+  }
+  __syncthreads();
+  const size_t base = (size_t)o * K * T;
+  const int n = K * T;
+  if ((n & 3) == 0) {
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w + base);
+    f32x4 *g4 = reinterpret_cast<f32x4 *>(gw + base);
+    for (int e = threadIdx.x; e < n / 4; e += 256) {
+      f32x4 v = w4[e];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] *= Mrow[(4 * e + c) / T];
+      if (accumulate) v += g4[e];
+      g4[e] = v;
+    }
+  } else {
+    for (int e = threadIdx.x; e < n; e += 256) {
+      const float v = w[base + e] * Mrow[e / T];
+      gw[base + e] = accumulate ? gw[base + e] + v : v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -546,6 +593,17 @@ int hg_channel_sum(const float *g, float *out, int32_t B, int32_t C, int32_t HW,
   hipLaunchKernelGGL(k_channel_sum, dim3(chunks, C), dim3(256), 0, st, g, (float *)workspace, B, C, HW);
   HG_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_plane_sum_finish, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)workspace, out, C, chunks);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+int hg_demod_weight_term(const float *w, const float *gd, const float *d, const float *s1, float *gw, int32_t B,
+                         int32_t N, int32_t K, int32_t taps, int32_t accumulate, void *stream) {
+  if (!w || !gd || !d || !s1 || !gw || B <= 0 || N <= 0 || K <= 0 || taps <= 0) return HG_EINVAL;
+  const size_t lds = (size_t)(K + B) * sizeof(float);
+  if (lds > 64 * 1024) return HG_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_demod_weight_term, dim3((unsigned)N), dim3(256), lds, (hipStream_t)stream, w, gd, d, s1, gw, B, N,
+                     K, taps, accumulate);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }

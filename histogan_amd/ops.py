@@ -12,6 +12,7 @@ from ._lib import check, lib, on_device, raw_stream
 
 
 KEEP_CONV = __import__('os').environ.get('HG_DNL_KEEP_CONV', '1') != '0'
+SKINNY_SPLIT = __import__('os').environ.get('HG_SKINNY_SPLIT', '1') != '0'   # _skinny_mm: chunked bmm + sum (0: plain mm)
 
 
 def _st(t):
@@ -168,7 +169,7 @@ class _ModConvStage(torch.autograd.Function):
         d = None
         if demod:
             wsq = C.cached(w, 'wsq', lambda t: t.pow(2).sum(dim=(2, 3)))
-            d = torch.rsqrt(torch.mm(s1 * s1, wsq.t()) + 1e-8)
+            d = torch.rsqrt(_skinny_mm(s1 * s1, wsq, True) + 1e-8)
         if act:
             nzt_, wn_, bn_ = _f32c(nzt.detach()), _f32c(wn.detach().reshape(-1)), _f32c(bn.detach())
             S = nzt_.shape[-1]
@@ -241,6 +242,20 @@ def modconv_stage(x, style, weight, nzt=None, wn=None, bn=None, demod=True, upsa
     return _ModConvStage.apply(x, style, weight, nzt, wn, bn, demod, upsample, act)
 
 
+def _skinny_mm(a, m, m_transposed):
+    """a (B, R) @ M (R, C) for a small B and a deep reduction R, M = m (R, C) or m.t() with m (C, R), m contiguous.
+    rocBLAS has no split-K pick for these: 32 x 2048 x 2048 runs as 64 workgroups, 60 us forward / 320 us for the
+    transposed operand; as S batches over chunks of R (a strided bmm, no copies) plus a sum it is S times the workgroups."""
+    B, R = a.shape
+    S = min(16, R // 128)
+    if not SKINNY_SPLIT or S < 4 or R % S or not m.is_contiguous() or not a.is_contiguous():
+        return torch.mm(a, m.t() if m_transposed else m)
+    r = R // S
+    av = a.view(B, S, r).transpose(0, 1)
+    mv = m.view(m.shape[0], S, r).permute(1, 2, 0) if m_transposed else m.view(S, r, m.shape[1])
+    return torch.bmm(av, mv).sum(0)
+
+
 class _DemodCoeff(torch.autograd.Function):
     """d[b,o] = rsqrt( sum_i (y[b,i]+1)^2 * wsq[o,i] + 1e-8 ),  wsq[o,i] = sum_k W[o,i,k]^2   (Conv2DMod demodulation,
     histoGAN/histoGAN.py:427-429, on the shared weight).  wsq only depends on the weight, so it is cached per optimizer
@@ -252,7 +267,7 @@ class _DemodCoeff(torch.autograd.Function):
         w = weight.detach()
         wsq = C.cached(w, 'wsq', lambda t: t.pow(2).sum(dim=(2, 3)))
         s1 = y.detach() + 1.0
-        d = torch.rsqrt(torch.mm(s1 * s1, wsq.t()) + 1e-8)
+        d = torch.rsqrt(_skinny_mm(s1 * s1, wsq, True) + 1e-8)
         ctx.save_for_backward(s1, wsq, d, w)
         return d
 
@@ -262,12 +277,12 @@ class _DemodCoeff(torch.autograd.Function):
         gq = gd * (-0.5) * d * d * d
         gy = gw = None
         if ctx.needs_input_grad[0]:
-            gy = 2.0 * s1 * torch.mm(gq, wsq)
+            gy = 2.0 * s1 * _skinny_mm(gq, wsq, False)
         if ctx.needs_input_grad[1]:
             from . import conv as C
-            M = torch.mm(gq.t(), s1 * s1)
-            if not C.direct_weight_term(w, M, 2.0):     # training: added to the flat gradient slot on the side stream
-                gw = 2.0 * w * M[:, :, None, None]
+            # training: added to the weight's flat gradient slot on the side stream (one kernel, hg_demod_weight_term)
+            if not (w.is_contiguous() and C.direct_demod_weight_term(w, gd, d, s1)):
+                gw = 2.0 * w * torch.mm(gq.t(), s1 * s1)[:, :, None, None]
         return gy, gw
 
 

@@ -64,6 +64,13 @@ int hg_channel_sum(const float *g, float *out, int32_t B, int32_t C, int32_t HW,
 int hg_lrelu_bwd_channel_sum(const float *g, const float *out, float slope, float *gm, float *csum, int32_t B, int32_t C,
                              int32_t HW, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Demodulation backward, weight side (Conv2DMod, histoGAN/histoGAN.py:427-429 on the shared weight; autograd's backward
+ * of `d = rsqrt(sum((w * (s+1))^2) + eps)` with respect to w):
+ *   gw[o,i,t] (+)= 2 w[o,i,t] sum_b gq[b,o] s1[b,i]^2,   gq = gd * (-0.5) * d^3,   s1 = style + 1
+ * w, gw (N, K, taps) contiguous; gd, d (B, N); s1 (B, K).  accumulate != 0: added to gw, else gw is overwritten. */
+int hg_demod_weight_term(const float *w, const float *gd, const float *d, const float *s1, float *gw, int32_t B,
+                         int32_t N, int32_t K, int32_t taps, int32_t accumulate, void *stream);
+
 /* Fused multi-tensor DiffGrad step over one flat parameter buffer of n floats:
  *   m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  dfc = 1/(1+exp(-|g_prev-g|));  g_prev = g
  *   p -= lr*sqrt(1-b2^t)/(1-b1^t) * (m*dfc) / (sqrt(v)+eps)                         (t = step >= 1) */

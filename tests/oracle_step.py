@@ -163,3 +163,69 @@ def lrelu_margin(sd_d, images, nblk):
                 from oracle import histogan_nets as N
                 x = N.image_linear_attention(sd, a + 'fn.', x) * sd[a + 'g'] + x
     return m
+
+
+class LreluMargin:
+    """Context manager: while active, every LeakyReLU of the oracle networks (oracle.histogan_nets.lrelu) on a feature map
+    records min |pre-activation| / max |pre-activation|; `.value` is the smallest seen.  Run around an fp64 oracle pass to
+    learn how far the closest pre-activation of that input is from zero (see lrelu_margin)."""
+
+    def __init__(self):
+        self.value = 1.0
+
+    def __enter__(self):
+        from oracle import histogan_nets as N
+        self._N, self._orig = N, N.lrelu
+
+        def hooked(x):
+            if x.dim() == 4:
+                a = x.detach().abs()
+                self.value = min(self.value, float(a.min() / a.max()))
+            return self._orig(x)
+
+        N.lrelu = hooked
+        return self
+
+    def __exit__(self, *exc):
+        self._N.lrelu = self._orig
+        return False
+
+
+class LreluMasks:
+    """Same-branch comparison for LeakyReLU networks.  An fp32 evaluation and the fp64 oracle disagree on the slope of the
+    few pre-activations that lie within fp32 rounding of zero (at 256^2 / capacity 16 / B = 2 the generator has 11 M of
+    them, the closest ~1e-8 of its layer's maximum, so most input draws have a handful), and ONE such pixel moves small
+    gradient tensors (to_noise, the 4x4 ... 16x16 weights) by 1e-3 -- for aten's fp32 as for ours (tools/skinny_check.py:
+    5 of 8 draws).  That is a property of fp32, not an arithmetic error, and it makes a max-norm gradient bar a coin toss.
+    So the oracle is evaluated on the SAME branches: `masks` (out > 0 of every feature-map LeakyReLU of the run under
+    test, in call order) replace the oracle's own sign decisions; what is left is arithmetic error.  `flips` counts the
+    disagreeing elements and `flip_margin` the largest |pre| / max|pre| among them (they must all be rounding-sized)."""
+
+    def __init__(self, masks):
+        self.masks, self.k, self.flips, self.flip_margin, self.total = list(masks), 0, 0, 0.0, 0
+
+    def __enter__(self):
+        from oracle import histogan_nets as N
+        self._N, self._orig = N, N.lrelu
+
+        def hooked(x):
+            if x.dim() != 4:
+                return self._orig(x)
+            m = self.masks[self.k]
+            self.k += 1
+            assert m.shape == x.shape, (m.shape, x.shape)
+            own = x.detach() > 0
+            diff = own != m
+            n = int(diff.sum())
+            self.total += x.numel()
+            if n:
+                self.flips += n
+                self.flip_margin = max(self.flip_margin, float(x.detach().abs()[diff].max() / x.detach().abs().max()))
+            return torch.where(m, x, 0.2 * x)
+
+        N.lrelu = hooked
+        return self
+
+    def __exit__(self, *exc):
+        self._N.lrelu = self._orig
+        return False

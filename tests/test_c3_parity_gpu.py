@@ -120,14 +120,8 @@ def test_c3_generator_matches_fp64_oracle(gpu_device):
             blk.to_noise1.weight.normal_(std=0.3); blk.to_noise2.weight.normal_(std=0.3)
             blk.to_noise1.bias.normal_(std=0.1); blk.to_noise2.bias.normal_(std=0.1)
     L = G.num_layers
-    styles = torch.randn(B, L - 2, LAT, device=dev, requires_grad=True)
-    hists = torch.randn(B, 2, LAT, device=dev, requires_grad=True)
-    noise = torch.rand(B, S_, S_, 1, device=dev)
-    go = torch.randn(B, 3, S_, S_, device=dev)
     names = [n for n, _ in G.named_parameters()]
     params = dict(G.named_parameters())
-    rgb = G(styles, hists, noise)
-    grads = torch.autograd.grad(rgb, [styles, hists] + [params[n] for n in names], go)
 
     def oracle(dt):
         sd = _sd(G, dev, dt)
@@ -136,7 +130,33 @@ def test_c3_generator_matches_fp64_oracle(gpu_device):
         gr = torch.autograd.grad(o, [st, hi] + [sd[n] for n in names], go.to(dt))
         return o.detach(), gr
 
-    t_rgb, t_gr = oracle(torch.float64)
+    # The fp64 oracle is evaluated on the LeakyReLU branches OUR forward took (oracle_step.LreluMasks): the handful of
+    # pre-activations within fp32 rounding of zero -- a property of fp32 any implementation has -- would otherwise decide
+    # the test by the draw; the disagreeing elements are counted and must all be rounding-sized.
+    from histogan_amd import ops
+    from oracle_step import LreluMasks
+    g = torch.Generator(device='cpu').manual_seed(21)
+    styles = torch.randn(B, L - 2, LAT, generator=g).to(dev).requires_grad_(True)
+    hists = torch.randn(B, 2, LAT, generator=g).to(dev).requires_grad_(True)
+    noise = torch.rand(B, S_, S_, 1, generator=g).to(dev)
+    go = torch.randn(B, 3, S_, S_, generator=g).to(dev)
+    masks, orig_dnl = [], ops.demod_noise_lrelu
+
+    def recording_dnl(*a):
+        out = orig_dnl(*a)
+        masks.append(out.detach() > 0)
+        return out
+
+    ops.demod_noise_lrelu = recording_dnl
+    try:
+        rgb = G(styles, hists, noise)
+    finally:
+        ops.demod_noise_lrelu = orig_dnl
+    assert len(masks) == 2 * len(G.blocks)
+    grads = torch.autograd.grad(rgb, [styles, hists] + [params[n] for n in names], go)
+    with LreluMasks(masks) as lm:
+        t_rgb, t_gr = oracle(torch.float64)
+    assert lm.k == len(masks) and lm.flips <= 1e-5 * lm.total and lm.flip_margin <= 2e-6, (lm.flips, lm.total, lm.flip_margin)
     r_rgb, r_gr = oracle(torch.float32)
     e_out = _rel(rgb.detach(), t_rgb)
     worst = max(((_rel(a, t), n) for a, t, n in zip(grads, t_gr, ['styles', 'hists'] + names)))
@@ -144,7 +164,7 @@ def test_c3_generator_matches_fp64_oracle(gpu_device):
     ref_rms = max(_rms(a, t) for a, t in zip(r_gr, t_gr))
     _record('generator', dict(out_ours=e_out, out_ref32=_rel(r_rgb, t_rgb), grad_worst=worst[0], grad_worst_name=worst[1],
                               grad_worst_ref32=max(_rel(a, t) for a, t in zip(r_gr, t_gr)), grad_rms_ours=ours_rms,
-                              grad_rms_ref32=ref_rms))
+                              grad_rms_ref32=ref_rms, lrelu_flips=lm.flips, lrelu_total=lm.total, lrelu_flip_margin=lm.flip_margin))
     assert e_out <= 1e-5
     assert worst[0] <= 1e-4, worst
     assert ours_rms <= 2 * ref_rms + 1e-7

@@ -311,3 +311,27 @@ def test_splitk_launches_are_deterministic_and_exact(B, K, N, H, gpu_device):
     assert all(torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) for o in outs[1:])
     ref = F.conv2d(x.detach().double(), w.detach().double(), padding=1)
     assert relmax(outs[0][0].cpu().numpy(), ref.cpu().numpy()) <= 5e-6
+
+
+@pytest.mark.parametrize('B,N,K,k', [(32, 64, 48, 3), (4, 5, 3, 3), (3, 7, 6, 1), (32, 1024, 2048, 3), (2, 33, 17, 1)])
+def test_demod_weight_term_kernel_matches_fp64(B, N, K, k, gpu_device):
+    """hg_demod_weight_term (the demodulation coefficient's weight gradient, written / accumulated into the flat gradient
+    slot) against the aten formula of ops._DemodCoeff.backward in fp64 (reference: autograd through
+    histoGAN/histoGAN.py:427-429)."""
+    from histogan_amd._lib import check, lib, raw_stream
+    g = torch.Generator(device='cpu').manual_seed(B + 7 * N + 13 * K + k)
+    w = (torch.randn(N, K, k, k, generator=g) / (K * k * k) ** 0.5).to(gpu_device)
+    s1 = (torch.randn(B, K, generator=g) * 0.5 + 1.0).to(gpu_device)
+    gd = torch.randn(B, N, generator=g).to(gpu_device)
+    d = torch.rsqrt(((s1 * s1) @ w.pow(2).sum(dim=(2, 3)).t()) + 1e-8)
+    wd, sd, gdd, dd = (t.double() for t in (w, s1, gd, d))
+    ref = 2.0 * wd * ((gdd * (-0.5) * dd ** 3).t() @ (sd * sd))[:, :, None, None]
+    prior = torch.randn(N, K, k, k, generator=g).to(gpu_device)
+    for acc in (0, 1):
+        out = prior.clone()
+        check(lib.hg_demod_weight_term(w.data_ptr(), gd.data_ptr(), d.data_ptr(), s1.data_ptr(), out.data_ptr(), B, N, K,
+                                       k * k, acc, raw_stream(gpu_device)), 'hg_demod_weight_term')
+        want = ref + prior.double() if acc else ref
+        assert relmax(out.cpu().numpy(), want.cpu().numpy()) <= 2e-6, acc
+    assert lib.hg_demod_weight_term(None, gd.data_ptr(), d.data_ptr(), s1.data_ptr(), prior.data_ptr(), B, N, K, k * k, 0,
+                                    raw_stream(gpu_device)) != 0
