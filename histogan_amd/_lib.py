@@ -80,6 +80,10 @@ def _load():
     lib.hg_demod_noise_lrelu_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]
     lib.hg_lrelu_bwd_channel_sum.restype = ctypes.c_int
     lib.hg_lrelu_bwd_channel_sum.argtypes = [vp, vp, f32, vp, vp, i32, i32, i32, vp, sz, vp]
+    lib.hg_demod_style_grad_workspace_bytes.restype = ctypes.c_size_t
+    lib.hg_demod_style_grad_workspace_bytes.argtypes = [i32, i32, i32]
+    lib.hg_demod_style_grad.restype = ctypes.c_int
+    lib.hg_demod_style_grad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, sz, vp]
     lib.hg_demod_weight_term.restype = ctypes.c_int
     lib.hg_demod_weight_term.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.hg_diffgrad_step.restype = ctypes.c_int
@@ -154,7 +158,7 @@ lib = _load()
 EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_uses_proj_cache', 'hg_rgbuv_hist_fwd',
            'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd', 'hg_selftest_fastlog',
            'hg_modulate_fwd', 'hg_modulate_bwd', 'hg_demod_noise_lrelu_fwd', 'hg_demod_noise_lrelu_bwd',
-           'hg_diffgrad_step', 'hg_diffgrad_step_size', 'hg_diffgrad_step_dev', 'hg_ema_update', 'hg_nets_workspace_bytes', 'hg_channel_sum', 'hg_lrelu_bwd_channel_sum', 'hg_demod_weight_term',
+           'hg_diffgrad_step', 'hg_diffgrad_step_size', 'hg_diffgrad_step_dev', 'hg_ema_update', 'hg_nets_workspace_bytes', 'hg_channel_sum', 'hg_lrelu_bwd_channel_sum', 'hg_demod_weight_term', 'hg_demod_style_grad', 'hg_demod_style_grad_workspace_bytes',
            'hg_conv_packed_elems', 'hg_conv_pack_weights', 'hg_conv_pack_weights_both', 'hg_conv_pack_blocks', 'hg_conv_pack_weights_multi', 'hg_conv2d_fwd', 'hg_conv2d_fwd_add', 'hg_modconv2d_fwd', 'hg_conv2d_workspace_bytes', 'hg_conv2d_plan', 'hg_conv2d_dgrad',
            'hg_conv2d_wgrad_workspace_bytes',
            'hg_conv2d_wgrad', 'hg_conv_b6_packed_bytes', 'hg_conv_b6_pack_weights', 'hg_conv2d_b6', 'hg_conv2d_b9',

@@ -490,6 +490,68 @@ __global__ __launch_bounds__(256) void k_demod_weight_term(const float *__restri
   }
 }
 
+// Demodulation backward, style side:  gy[b,i] = 2 s1[b,i] sum_o gq[b,o] wsq[o,i],  gq = gd * (-0.5) * d^3,
+// wsq[o,i] = sum_t w[o,i,t]^2.  A (B x N) @ (N x K) product with B = 32: rocBLAS runs it as 64 workgroups without a split
+// over the N-deep reduction (262 us at N = K = 2048, and no faster as a chunked batched GEMM) at the end of the
+// generator's backward chain.  Here: grid (K / 64 column tiles, NS row splits), a thread per column with B_T running sums,
+// gq's rows of the split in LDS; the NS partial results are summed in fixed order by k_demod_style_grad_finish.
+constexpr int DSG_BT = 32;   // batch rows per pass
+__global__ __launch_bounds__(256) void k_demod_style_grad(const float *__restrict__ gd, const float *__restrict__ d,
+                                                          const float *__restrict__ wsq, float *__restrict__ part, int B,
+                                                          int N, int K, int rows_per) {
+  extern __shared__ float dsm[];
+  float *gq = dsm;                       // [rows_per][DSG_BT]
+  float *red = dsm + rows_per * DSG_BT;  // [4][DSG_BT][64]
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + tx;
+  const int o0 = blockIdx.y * rows_per, o1 = min(N, o0 + rows_per);
+  for (int b0 = 0; b0 < B; b0 += DSG_BT) {
+    const int nb = min(DSG_BT, B - b0);
+    __syncthreads();
+    for (int e = threadIdx.x; e < (o1 - o0) * DSG_BT; e += 256) {
+      const int r = e / DSG_BT, b = e - r * DSG_BT;
+      float v = 0.f;
+      if (b < nb) {
+        const float dd = d[(size_t)(b0 + b) * N + o0 + r];
+        v = gd[(size_t)(b0 + b) * N + o0 + r] * (-0.5f) * dd * dd * dd;
+      }
+      gq[e] = v;
+    }
+    __syncthreads();
+    float acc[DSG_BT];
+#pragma unroll
+    for (int b = 0; b < DSG_BT; ++b) acc[b] = 0.f;
+    if (i < K) {
+      for (int o = o0 + ty; o < o1; o += 4) {
+        const float w = wsq[(size_t)o * K + i];
+        const float *g = gq + (o - o0) * DSG_BT;
+#pragma unroll
+        for (int b = 0; b < DSG_BT; ++b) acc[b] = fmaf(g[b], w, acc[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < DSG_BT; ++b) red[(ty * DSG_BT + b) * 64 + tx] = acc[b];
+    __syncthreads();
+    // [4][BT][64] -> part[split][b][i]: fixed-order sum of the 4 row groups
+    for (int e = threadIdx.x; e < DSG_BT * 64; e += 256) {
+      const int b = e >> 6, c = e & 63;
+      if (b < nb && blockIdx.x * 64 + c < K)
+        part[((size_t)blockIdx.y * B + b0 + b) * K + blockIdx.x * 64 + c] =
+            (red[(0 * DSG_BT + b) * 64 + c] + red[(1 * DSG_BT + b) * 64 + c]) +
+            (red[(2 * DSG_BT + b) * 64 + c] + red[(3 * DSG_BT + b) * 64 + c]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_demod_style_grad_finish(const float *__restrict__ part, const float *__restrict__ s1,
+                                                                 float *__restrict__ gy, int BK, int splits) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= BK) return;
+  float v = 0.f;
+  for (int z = 0; z < splits; ++z) v += part[(size_t)z * BK + e];
+  gy[e] = 2.f * s1[e] * v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -593,6 +655,34 @@ int hg_channel_sum(const float *g, float *out, int32_t B, int32_t C, int32_t HW,
   hipLaunchKernelGGL(k_channel_sum, dim3(chunks, C), dim3(256), 0, st, g, (float *)workspace, B, C, HW);
   HG_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_plane_sum_finish, dim3((C + 255) / 256), dim3(256), 0, st, (const float *)workspace, out, C, chunks);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+static int demod_style_splits(int N) {
+  int ns = (N + 63) / 64;   // <= 64 rows of gq per block in LDS (up to N = 4096)
+  return ns > 64 ? 64 : (ns < 1 ? 1 : ns);
+}
+
+size_t hg_demod_style_grad_workspace_bytes(int32_t B, int32_t N, int32_t K) {
+  if (B <= 0 || N <= 0 || K <= 0) return 0;
+  return (size_t)demod_style_splits(N) * B * K * sizeof(float);
+}
+
+int hg_demod_style_grad(const float *gd, const float *d, const float *s1, const float *wsq, float *gy, int32_t B, int32_t N,
+                        int32_t K, void *workspace, size_t workspace_bytes, void *stream) {
+  if (!gd || !d || !s1 || !wsq || !gy || B <= 0 || N <= 0 || K <= 0) return HG_EINVAL;
+  if (!workspace || workspace_bytes < hg_demod_style_grad_workspace_bytes(B, N, K)) return HG_EWORKSPACE;
+  const int ns = demod_style_splits(N), rows_per = (N + ns - 1) / ns;
+  const size_t lds = ((size_t)rows_per * DSG_BT + 4 * DSG_BT * 64) * sizeof(float);
+  if (lds > 64 * 1024) return HG_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_demod_style_grad, dim3((unsigned)((K + 63) / 64), (unsigned)ns), dim3(256), lds, st, gd, d, wsq,
+                     (float *)workspace, B, N, K, rows_per);
+  HG_LAUNCH_CHECK();
+  const int BK = B * K;
+  hipLaunchKernelGGL(k_demod_style_grad_finish, dim3((unsigned)((BK + 255) / 256)), dim3(256), 0, st,
+                     (const float *)workspace, s1, gy, BK, ns);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }

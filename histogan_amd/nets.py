@@ -408,5 +408,11 @@ class Discriminator(nn.Module):
             if q_block is not None:
                 x, loss = q_block(x)
                 quantize_loss = quantize_loss + loss
-        x = self.to_logit(self.flatten(x))
+        x = self.flatten(x)
+        if x.is_cuda and ops.SKINNY_SPLIT and self.to_logit.out_features == 1:
+            # (B x 8192) @ (8192 x 1): rocBLAS runs the logit layer as ONE workgroup walking the whole reduction, 100 us at the
+            # end of every discriminator forward; a product and a row sum are two short memory-bound launches
+            x = (x * self.to_logit.weight).sum(dim=1, keepdim=True) + self.to_logit.bias
+        else:
+            x = self.to_logit(x)
         return x.squeeze(), quantize_loss

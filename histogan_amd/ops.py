@@ -13,6 +13,7 @@ from ._lib import check, lib, on_device, raw_stream
 
 KEEP_CONV = __import__('os').environ.get('HG_DNL_KEEP_CONV', '1') != '0'
 SKINNY_SPLIT = __import__('os').environ.get('HG_SKINNY_SPLIT', '1') != '0'   # _skinny_mm: chunked bmm + sum (0: plain mm)
+FUSED_DEMOD_BWD = __import__('os').environ.get('HG_FUSED_DEMOD_BWD', '1') != '0'   # hg_demod_style_grad (0: aten ops)
 
 
 def _st(t):
@@ -274,14 +275,25 @@ class _DemodCoeff(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gd):
         s1, wsq, d, w = ctx.saved_tensors
-        gq = gd * (-0.5) * d * d * d
-        gy = gw = None
+        gy = gw = gq = None
+        fused = FUSED_DEMOD_BWD and gd.is_cuda and not torch.is_grad_enabled() and wsq.is_contiguous()
         if ctx.needs_input_grad[0]:
-            gy = 2.0 * s1 * _skinny_mm(gq, wsq, False)
+            if fused:       # one kernel pair (hg_demod_style_grad) instead of a skinny rocBLAS GEMM + five element-wise launches
+                gdc, B, N, K = _f32c(gd), d.shape[0], d.shape[1], s1.shape[1]
+                with on_device(gd.device):
+                    gy = torch.empty_like(s1)
+                    nb = lib.hg_demod_style_grad_workspace_bytes(B, N, K)
+                    ws = torch.empty(nb, dtype=torch.uint8, device=gd.device)
+                    check(lib.hg_demod_style_grad(gdc.data_ptr(), d.data_ptr(), s1.data_ptr(), wsq.data_ptr(), gy.data_ptr(),
+                                                  B, N, K, ws.data_ptr(), nb, _st(gd)), 'hg_demod_style_grad')
+            else:
+                gq = gd * (-0.5) * d * d * d
+                gy = 2.0 * s1 * _skinny_mm(gq, wsq, False)
         if ctx.needs_input_grad[1]:
             from . import conv as C
             # training: added to the weight's flat gradient slot on the side stream (one kernel, hg_demod_weight_term)
             if not (w.is_contiguous() and C.direct_demod_weight_term(w, gd, d, s1)):
+                gq = gd * (-0.5) * d * d * d if gq is None else gq
                 gw = 2.0 * w * torch.mm(gq.t(), s1 * s1)[:, :, None, None]
         return gy, gw
 

@@ -64,6 +64,13 @@ int hg_channel_sum(const float *g, float *out, int32_t B, int32_t C, int32_t HW,
 int hg_lrelu_bwd_channel_sum(const float *g, const float *out, float slope, float *gm, float *csum, int32_t B, int32_t C,
                              int32_t HW, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Demodulation backward, style side (autograd's backward of the Conv2DMod demodulation coefficient with respect to the
+ * style, histoGAN/histoGAN.py:427-429):  gy[b,i] = 2 s1[b,i] sum_o gq[b,o] wsq[o,i],  gq = gd * (-0.5) * d^3,
+ * wsq[o,i] = sum_t w[o,i,t]^2 (N, K);  gd, d (B, N);  s1 = style + 1, gy (B, K).  Deterministic (fixed-order partial sums). */
+size_t hg_demod_style_grad_workspace_bytes(int32_t B, int32_t N, int32_t K);
+int hg_demod_style_grad(const float *gd, const float *d, const float *s1, const float *wsq, float *gy, int32_t B, int32_t N,
+                        int32_t K, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Demodulation backward, weight side (Conv2DMod, histoGAN/histoGAN.py:427-429 on the shared weight; autograd's backward
  * of `d = rsqrt(sum((w * (s+1))^2) + eps)` with respect to w):
  *   gw[o,i,t] (+)= 2 w[o,i,t] sum_b gq[b,o] s1[b,i]^2,   gq = gd * (-0.5) * d^3,   s1 = style + 1

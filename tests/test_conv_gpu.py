@@ -335,3 +335,26 @@ def test_demod_weight_term_kernel_matches_fp64(B, N, K, k, gpu_device):
         assert relmax(out.cpu().numpy(), want.cpu().numpy()) <= 2e-6, acc
     assert lib.hg_demod_weight_term(None, gd.data_ptr(), d.data_ptr(), s1.data_ptr(), prior.data_ptr(), B, N, K, k * k, 0,
                                     raw_stream(gpu_device)) != 0
+
+
+@pytest.mark.parametrize('B,N,K', [(32, 64, 48), (4, 5, 3), (32, 2048, 2048), (2, 1024, 2048), (40, 130, 70), (3, 4100, 65)])
+def test_demod_style_grad_kernel_matches_fp64(B, N, K, gpu_device):
+    """hg_demod_style_grad (the demodulation coefficient's style gradient) against the aten formula in fp64; B above the
+    kernel's 32-row pass, N above one 64-row split table, ragged K."""
+    from histogan_amd._lib import check, lib, raw_stream
+    g = torch.Generator(device='cpu').manual_seed(3 * B + 7 * N + 13 * K)
+    wsq = (torch.rand(N, K, generator=g) / K).to(gpu_device)
+    s1 = (torch.randn(B, K, generator=g) * 0.5 + 1.0).to(gpu_device)
+    gd = torch.randn(B, N, generator=g).to(gpu_device)
+    d = torch.rsqrt((s1 * s1) @ wsq.t() + 1e-8)
+    ref = 2.0 * s1.double() * ((gd.double() * (-0.5) * d.double() ** 3) @ wsq.double())
+    gy = torch.full((B, K), float('nan'), device=gpu_device)
+    nb = lib.hg_demod_style_grad_workspace_bytes(B, N, K)
+    ws = torch.empty(nb, dtype=torch.uint8, device=gpu_device)
+    args = (gd.data_ptr(), d.data_ptr(), s1.data_ptr(), wsq.data_ptr(), gy.data_ptr(), B, N, K, ws.data_ptr())
+    check(lib.hg_demod_style_grad(*args, nb, raw_stream(gpu_device)), 'hg_demod_style_grad')
+    assert relmax(gy.cpu().numpy(), ref.cpu().numpy()) <= 2e-6
+    first = gy.clone()
+    check(lib.hg_demod_style_grad(*args, nb, raw_stream(gpu_device)), 'hg_demod_style_grad')
+    assert torch.equal(first, gy)                                   # fixed summation order
+    assert lib.hg_demod_style_grad(*args, nb - 4, raw_stream(gpu_device)) != 0      # workspace too small
