@@ -52,6 +52,8 @@ EPS = 1e-8
 EXTS = ['jpg', 'png']
 G_OVERLAP = os.environ.get('HG_G_OVERLAP', '1') != '0'   # G-phase generator forward on a second stream beside the D phase
 G_STREAM_PRIO = int(os.environ.get('HG_G_STREAM_PRIO', '0'))   # HIP priority of that stream (0 normal, -1 high)
+H_SIDE = os.environ.get('HG_H_SIDE', '1') != '0'               # D phase: histogram vectorizer on a second stream beside S
+BATCH_S = os.environ.get('HG_BATCH_S', '1') != '0'             # both latent batches of a mixed draw through S at once
 D_STEP_EARLY = os.environ.get('HG_D_STEP_EARLY', '1') != '0'   # D's optimizer step before main waits for that stream
 # Plain steps replayed from a captured hipGraph (single process): HG_GRAPH = auto (default) | 1 | 0 | 2.
 #   auto: decided from the first eager plain steps -- the graph is used when the host's enqueue work IS the step (small
@@ -182,6 +184,12 @@ class _Rng:
 
 
 def latent_to_w(style_vectorizer, latent_descr):
+    zs = [z for z, _ in latent_descr]
+    if BATCH_S and len(zs) > 1 and zs[0].is_cuda and all(z.shape == zs[0].shape for z in zs):
+        # mixed latents (90 % of the steps): the two z batches through the 8-layer mapping network as ONE batch -- rows are
+        # independent, and the 16 launches it saves are serial ~15 us ones at the head of every generator forward
+        ws = style_vectorizer(torch.cat(zs, dim=0)).split(zs[0].shape[0], dim=0)
+        return [(w, num_layers) for w, (_, num_layers) in zip(ws, latent_descr)]
     return [(style_vectorizer(z), num_layers) for z, num_layers in latent_descr]
 
 
@@ -410,6 +418,21 @@ class Trainer():
 
     def _w_and_hw(self, style, hist_batch):
         GAN = self.GAN
+        if (H_SIDE and hist_batch.is_cuda and not torch.is_grad_enabled()
+                and not torch.cuda.is_current_stream_capturing()):
+            # no autograd (the D phase): the histogram vectorizer beside the mapping network instead of behind it -- two
+            # independent chains of 8 small serial GEMMs at the head of the generator forward
+            from .nets import aux_stream
+            main, aux = torch.cuda.current_stream(hist_batch.device), aux_stream(hist_batch.device)
+            aux.wait_event(main.record_event())
+            with torch.cuda.stream(aux):
+                h_w_space = torch.unsqueeze(GAN.H(hist_batch), dim=1)
+                h_w_space = torch.cat((h_w_space, h_w_space), dim=1)
+            hist_batch.record_stream(aux)
+            w_space = styles_def_to_tensor(latent_to_w(GAN.S, style))
+            main.wait_stream(aux)
+            h_w_space.record_stream(main)
+            return w_space, h_w_space
         w_space = latent_to_w(GAN.S, style)
         h_w_space = GAN.H(hist_batch)
         h_w_space = torch.unsqueeze(h_w_space, dim=1)
@@ -475,8 +498,11 @@ class Trainer():
         """Style tensor (B, layers, 512) with a DEVICE-side split point: layers < tt from latent 1, the rest from latent 2
         (`styles_def_to_tensor(latent_to_w(S, mixed_list(...)))` of the reference, :166-189, with the launch sequence
         independent of the draw)."""
-        w1 = self.GAN.S(self.rng.noise(batch_size, latent_dim))
-        w2 = self.GAN.S(self.rng.noise(batch_size, latent_dim))
+        z1, z2 = self.rng.noise(batch_size, latent_dim), self.rng.noise(batch_size, latent_dim)
+        if BATCH_S:
+            w1, w2 = self.GAN.S(torch.cat((z1, z2), dim=0)).split(batch_size, dim=0)
+        else:
+            w1, w2 = self.GAN.S(z1), self.GAN.S(z2)
         first = (torch.arange(layers, device=self.device) < tt_dev).view(1, layers, 1)
         return torch.where(first, w1[:, None, :], w2[:, None, :])
 
