@@ -496,26 +496,28 @@ __global__ __launch_bounds__(256) void k_demod_weight_term(const float *__restri
 // generator's backward chain.  Here: grid (K / 64 column tiles, NS row splits), a thread per column with B_T running sums,
 // gq's rows of the split in LDS; the NS partial results are summed in fixed order by k_demod_style_grad_finish.
 constexpr int DSG_BT = 32;   // batch rows per pass
+constexpr int DSG_LD = DSG_BT + 1;   // LDS pitch of a gq row (odd: the transposing fill is conflict-free)
 __global__ __launch_bounds__(256) void k_demod_style_grad(const float *__restrict__ gd, const float *__restrict__ d,
                                                           const float *__restrict__ wsq, float *__restrict__ part, int B,
                                                           int N, int K, int rows_per) {
   extern __shared__ float dsm[];
-  float *gq = dsm;                       // [rows_per][DSG_BT]
-  float *red = dsm + rows_per * DSG_BT;  // [4][DSG_BT][64]
+  float *gq = dsm;                       // [rows_per][DSG_LD]
+  float *red = dsm + rows_per * DSG_LD;  // [4][DSG_BT][64]
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + tx;
   const int o0 = blockIdx.y * rows_per, o1 = min(N, o0 + rows_per);
   for (int b0 = 0; b0 < B; b0 += DSG_BT) {
     const int nb = min(DSG_BT, B - b0);
     __syncthreads();
-    for (int e = threadIdx.x; e < (o1 - o0) * DSG_BT; e += 256) {
-      const int r = e / DSG_BT, b = e - r * DSG_BT;
+    const int rows = o1 - o0;
+    for (int e = threadIdx.x; e < rows * DSG_BT; e += 256) {
+      const int b = e / rows, r = e - b * rows;      // consecutive threads: consecutive channels of one batch row (coalesced)
       float v = 0.f;
       if (b < nb) {
         const float dd = d[(size_t)(b0 + b) * N + o0 + r];
         v = gd[(size_t)(b0 + b) * N + o0 + r] * (-0.5f) * dd * dd * dd;
       }
-      gq[e] = v;
+      gq[r * DSG_LD + b] = v;
     }
     __syncthreads();
     float acc[DSG_BT];
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256) void k_demod_style_grad(const float *__restric
     if (i < K) {
       for (int o = o0 + ty; o < o1; o += 4) {
         const float w = wsq[(size_t)o * K + i];
-        const float *g = gq + (o - o0) * DSG_BT;
+        const float *g = gq + (o - o0) * DSG_LD;
 #pragma unroll
         for (int b = 0; b < DSG_BT; ++b) acc[b] = fmaf(g[b], w, acc[b]);
       }
@@ -674,7 +676,7 @@ int hg_demod_style_grad(const float *gd, const float *d, const float *s1, const 
   if (!gd || !d || !s1 || !wsq || !gy || B <= 0 || N <= 0 || K <= 0) return HG_EINVAL;
   if (!workspace || workspace_bytes < hg_demod_style_grad_workspace_bytes(B, N, K)) return HG_EWORKSPACE;
   const int ns = demod_style_splits(N), rows_per = (N + ns - 1) / ns;
-  const size_t lds = ((size_t)rows_per * DSG_BT + 4 * DSG_BT * 64) * sizeof(float);
+  const size_t lds = ((size_t)rows_per * DSG_LD + 4 * DSG_BT * 64) * sizeof(float);
   if (lds > 64 * 1024) return HG_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_demod_style_grad, dim3((unsigned)((K + 63) / 64), (unsigned)ns), dim3(256), lds, st, gd, d, wsq,
