@@ -145,6 +145,8 @@ def cached(w, tag, compute):
     hit = _cache.get((key, tag))
     st = _stamp(w, owner)
     if hit is not None and hit[0] == st:
+        if tag == 'wsq':
+            _await_pack(owner, w.device)
         return hit[1]
     if tag == 'wsq' and PACK_MULTI and w.is_cuda and _pack_owner(owner, w.device):
         # the batched packing launch of this weight's flat buffer also leaves sum_taps W^2 of every weight (hg_pack_item.wsq)
@@ -164,6 +166,7 @@ def pack_weights(w, mode):
         hit = _cache.get((key, mode))
         st = _stamp(w, owner)
         if hit is not None and hit[0] == st:
+            _await_pack(owner, w.device)
             return hit[1]
         # A registered (training) weight needs both operands once per optimizer step, and so do all its siblings in the
         # same flat buffer: ONE launch packs every convolution weight of that buffer (hg_conv_pack_weights_multi) the
@@ -228,8 +231,10 @@ def _pack_owner(owner, device, launch=True):
             plan = _multi[owner] = dict(sig=sig, bufs=bufs, table=raw.to(device), n=len(live), blocks=blocks)
         if not launch:
             return True
+        _await_pack(owner, device)         # an asynchronous pack of the same buffers still in flight goes first
         check(lib.hg_conv_pack_weights_multi(plan['table'].data_ptr(), plan['n'], plan['blocks'], raw_stream(device)),
               'hg_conv_pack_weights_multi')
+        _pack_events.pop(owner, None)      # (prepack_async records the event of THIS launch right after)
     for key, p in live:
         st = _stamp(p, owner)
         wf, wd, wq = plan['bufs'][key]
@@ -237,6 +242,40 @@ def _pack_owner(owner, device, launch=True):
         _cache[(key, PACK_DGRAD)] = (st, wd)
         _cache[(key, 'wsq')] = (st, wq)
     return True
+
+
+PREPACK = os.environ.get('HG_PREPACK', '1') != '0'
+_pack_streams = {}
+_pack_events = {}    # owner -> [event behind the asynchronous batched pack, ids of the streams that already wait for it]
+
+
+def prepack_async(flat):
+    """Pack the convolution weights of flat buffer `flat` NOW, on a stream of its own, instead of at their first use: after the
+    generator's optimizer step that first use is the first convolution of the next step's generator forward, behind the
+    mapping network's serial ~15 us launches -- the 0.2 ms packing launch runs under those.  Consumers wait for the pack's
+    event (_await_pack, once per stream); the launch itself is ordered behind everything enqueued on the current stream
+    (the readers of the operand buffers it overwrites)."""
+    if not (PREPACK and PACK_MULTI) or not flat.is_cuda or torch.cuda.is_current_stream_capturing():
+        return False
+    device, owner = flat.device, _owner_of(flat)
+    st = _pack_streams.get(device.index)
+    if st is None:
+        st = _pack_streams[device.index] = torch.cuda.Stream(device=device)
+    st.wait_event(torch.cuda.current_stream(device).record_event())
+    with torch.cuda.stream(st):
+        ok = _pack_owner(owner, device)
+        if ok:
+            _pack_events[owner] = [st.record_event(), {st.cuda_stream}]
+    return ok
+
+
+def _await_pack(owner, device):
+    ent = _pack_events.get(owner)
+    if ent is not None:
+        cur = torch.cuda.current_stream(device)
+        if cur.cuda_stream not in ent[1]:
+            cur.wait_event(ent[0])
+            ent[1].add(cur.cuda_stream)
 
 
 def pack_b6(w, mode):

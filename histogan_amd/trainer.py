@@ -43,7 +43,7 @@ from torch.autograd import grad as torch_grad
 
 from . import ddp
 from .augment import AugWrapper
-from .conv import enable_pack_cache, input_grads_only, weights_changed
+from .conv import enable_pack_cache, input_grads_only, prepack_async, weights_changed
 from .hist import hellinger_loss
 from .nets import Discriminator, Generator, HistVectorizer, StyleVectorizer
 from .optim import DiffGrad, FlatParams, ema_update
@@ -696,6 +696,7 @@ class Trainer():
         else:
             GAN._reduce_g()
             GAN.G_opt.step()
+        prepack_async(GAN._flat_g.data)        # next step's generator operands, under the head of its forward
 
         return torch.stack([total_disc_loss, total_gen_loss, total_hist_loss, gp_val.reshape(()),
                             q_val.reshape(()), pl_len if pl_len is not None else zero()]).double()
