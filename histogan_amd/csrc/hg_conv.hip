@@ -52,7 +52,8 @@
 #endif
 #ifndef HG_CONV_XCD_SPLITK
 // EXPERIMENT, compiled out by default (not validated on the full suite): the K-split slabs of k_conv combined by the last
-// arriving block of each tile, fence-free -- the splits of a tile share an XCD (see conv_body and DESIGN.md section 12.5)
+// arriving block of each tile, fence-free -- the splits of a tile share an XCD (see conv_body and DESIGN.md section 12.5).
+// 1: measured (correct, 48.5 vs 46.6 ms per step); 2: + a tile's splits adjacent in dispatch order (written, never run)
 #define HG_CONV_XCD_SPLITK 0
 #endif
 #ifndef HG_CONV_BIGTILE_SPLITK
@@ -555,7 +556,21 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, con
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM, int MT, bool FE>
 __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvArgs a) {
 #if HG_CONV_XCD_SPLITK
-  if ((int)blockIdx.x >= a.g.tiles_x * a.g.tiles_y * a.g.groups) return;   // spare blocks of the grid padded to 8 (XCD pairing)
+  if (a.flags != nullptr) {
+#if HG_CONV_XCD_SPLITK >= 2
+    // (written at the end of round 3, NOT yet run on hardware) 1-D grid, a tile's splits adjacent in dispatch order and on one
+    // XCD: linear id L = 8 (Z t + z) + x  ->  XCD x, split z, tile 8 t + x; the combine of one tile then runs under the K
+    // loops of the tiles dispatched behind it instead of at the tail of the launch.
+    const int L = (int)blockIdx.x, x8 = L & 7, sq = L >> 3;
+    const int z = sq % a.ksplit, T = (sq / a.ksplit) * 8 + x8;
+    const int gxr = a.g.tiles_x * a.g.tiles_y * a.g.groups;
+    if (T >= gxr * (int)((a.N + WC * TC * MT - 1) / (WC * TC * MT))) return;
+    conv_body<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, FE>(a, T % gxr, T / gxr, z);
+    return;
+#else
+    if ((int)blockIdx.x >= a.g.tiles_x * a.g.tiles_y * a.g.groups) return;   // spare blocks of the padded grid (XCD pairing)
+#endif
+  }
 #endif
   conv_body<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, FE>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
@@ -1368,7 +1383,13 @@ int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t
     for (unsigned d = 2; d <= 8; d *= 2) if (ny % d == 0) m = 8 / d;
     gx = (gx + m - 1) / m * m;
   }
-  const dim3 grid(gx, (unsigned)((a.N + NB - 1) / NB), (unsigned)ksplit);
+  dim3 grid(gx, (unsigned)((a.N + NB - 1) / NB), (unsigned)ksplit);
+#if HG_CONV_XCD_SPLITK >= 2
+  if (inkernel_combine) {
+    const unsigned tiles = (unsigned)(a.g.tiles_x * a.g.tiles_y * a.g.groups) * (unsigned)((a.N + NB - 1) / NB);
+    grid = dim3((tiles + 7u) / 8u * 8u * (unsigned)ksplit, 1, 1);
+  }
+#endif
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);
   HG_LAUNCH_CHECK();
   if (ksplit > 1 && reduce && !inkernel_combine) return launch_splitk_reduce(a, ksplit, st);
