@@ -57,3 +57,26 @@ def test_latent_to_w_layer_counts_and_fallback():
     assert torch.equal(out[0][0], S(z1)) and torch.equal(out[1][0], S(z2))
     t = T.styles_def_to_tensor(out)
     assert t.shape == (4, 5, 16) and torch.equal(t[:, 2], out[0][0]) and torch.equal(t[:, 3], out[1][0])
+
+
+def test_demod_backward_formulas_equal_autograd_of_the_reference_expression():
+    """The closed forms hg_demod_weight_term / hg_demod_style_grad implement (and the GPU tests compare the kernels with) are
+    the gradients of the reference's demodulation, histoGAN/histoGAN.py:427-429, written there on per-sample weights:
+        weights = w[None] * (y[:, None, :, None, None] + 1);  d = rsqrt((weights ** 2).sum(dim=(2, 3, 4)) + EPS)
+    Checked here against autograd of exactly that expression in fp64."""
+    g = torch.Generator().manual_seed(5)
+    B, N, K, k = 3, 6, 5, 3
+    w = torch.randn(N, K, k, k, generator=g, dtype=torch.float64, requires_grad=True)
+    y = torch.randn(B, K, generator=g, dtype=torch.float64, requires_grad=True)
+    gd = torch.randn(B, N, generator=g, dtype=torch.float64)
+    weights = w[None] * (y[:, None, :, None, None] + 1)
+    d = torch.rsqrt((weights ** 2).sum(dim=(2, 3, 4)) + 1e-8)
+    gy_ref, gw_ref = torch.autograd.grad(d, (y, w), gd)
+    with torch.no_grad():
+        s1 = y + 1
+        wsq = w.pow(2).sum(dim=(2, 3))
+        assert torch.allclose(torch.rsqrt((s1 * s1) @ wsq.t() + 1e-8), d, rtol=1e-12, atol=0)      # the shared-weight form of d
+        gq = gd * (-0.5) * d ** 3
+        gy = 2.0 * s1 * (gq @ wsq)                                   # hg_demod_style_grad
+        gw = 2.0 * w * (gq.t() @ (s1 * s1))[:, :, None, None]        # hg_demod_weight_term
+    assert torch.allclose(gy, gy_ref, rtol=1e-10, atol=1e-12) and torch.allclose(gw, gw_ref, rtol=1e-10, atol=1e-12)
