@@ -3,6 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload train|hist]
 
+`--gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset) starts N ranks itself, one per GPU (`launch_ranks`);
+under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one of the N ranks.
+
 Workload `train` (default; BASELINE.json configs[2], and configs[3] under --gpus 8): the full HistoGAN
 G+D train step (histogan_amd/trainer.py == reference Trainer.train, histoGAN/histoGAN.py:853-1020) at
 256^2, network_capacity 16, h=64, batch 32 PER GPU on resident synthetic data; the K timed steps
@@ -420,6 +423,58 @@ def claim_stdout():
     return os.fdopen(saved, 'w')
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def rank_env(base, rank, world, port):
+    """Environment of rank `rank` of a `world`-rank single-node job (what torch.distributed.run would export)."""
+    env = dict(base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('HG_BENCH_LAUNCHED', None)
+    env['HG_BENCH_LAUNCHED'] = '1'
+    return env
+
+
+def launch_ranks(n, argv, json_out, timeout=None):
+    """`python bench.py --gpus N` without an external launcher: start one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* as torch.distributed.run exports them), forward rank 0's single JSON line, return the worst exit code.
+    One rank per device is asserted up front (HG_DIST_BACKEND=gloo: ranks may share a device -- test use)."""
+    import subprocess
+    backend = os.environ.get('HG_DIST_BACKEND', 'nccl')
+    have = torch.cuda.device_count()
+    if backend == 'nccl' and have < n:
+        print(f'bench.py: --gpus {n} but only {have} GPU(s) visible (one process per GPU over RCCL; '
+              f'HG_DIST_BACKEND=gloo lets ranks share a device for tests)', file=sys.stderr)
+        return 2
+    port = free_port()
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=rank_env(os.environ, r, n, port),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    t_end = None if timeout is None else time.time() + timeout
+    rc, out0 = 0, b''
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout)
+        for p in procs:
+            p.wait(timeout=None if t_end is None else max(1.0, t_end - time.time()))
+            rc = rc or p.returncode
+    except subprocess.TimeoutExpired:
+        rc = 124
+    finally:
+        for p in procs:              # exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+    lines = [l for l in out0.decode(errors='replace').splitlines() if l.strip()]
+    if rc == 0 and lines:
+        print(lines[-1], file=json_out, flush=True)
+    return rc
+
+
 def main():
     json_out = claim_stdout()
     ap = argparse.ArgumentParser()
@@ -437,6 +492,10 @@ def main():
     ap.add_argument('--no-reference-eager', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='skip the stand-alone kernel timings (tests only)')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # no external launcher (torch.distributed.run exports WORLD_SIZE): one process per GPU from here
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], json_out))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

@@ -11,11 +11,10 @@ The reference is single-GPU (histoGAN.py:242,268); these semantics are new (SURV
   generator forward of the G phase (which does not touch D); it is waited for before D_opt.step();
 * scalar state that steers control flow (NaN flag, pl_mean) is all-reduced so ranks never diverge.
 """
+import os
+
 import torch
 import torch.distributed as dist
-
-
-import os
 
 # HG_DIST_FORCE=1: take the data-parallel code paths (broadcasts, gradient / statistics / Hellinger all-reduces) whenever
 # a process group exists, even at world size 1 -- lets a 1-GPU box run the whole step through RCCL (tests/test_bench_gpu.py)
@@ -77,6 +76,8 @@ class GradAllReduce:
         self.flat.gather()
         if not is_dist():
             return
+        if self._work:             # handles of a step that did not get to its wait (an exception in between): drain them
+            self.finish()
         g = self.flat.grad
         if _avg_in_collective():
             op = dist.ReduceOp.AVG

@@ -570,6 +570,7 @@ class Trainer():
             o.zero_grad()
             o.flat.direct_ok = False
         GAN._reduce_d.finish()
+        GAN._reduce_g.finish()
         weights_changed()
 
     def _device_step(self, alpha, apply_gradient_penalty, apply_path_penalty, gs=None):
@@ -611,8 +612,10 @@ class Trainer():
                 noise = self.rng.image_noise(batch_size, image_size)
             return noise, hist_batch, w_styles, h_w_space, GAN.G(w_styles, h_w_space, noise)
 
-        # (single-GPU runs only: under data parallelism the D-gradient all-reduce hides behind the G-phase forward instead)
-        overlap_g = G_OVERLAP and acc == 1 and not ddp.is_dist()
+        # (under data parallelism as well: the D-gradient all-reduce runs on RCCL's own stream beside both -- it waits for
+        # the gathered D gradients on the main stream and is waited for by D's optimizer step, neither of which the second
+        # stream's generator forward touches)
+        overlap_g = G_OVERLAP and acc == 1
         if overlap_g and not getattr(self, '_warn_off', False):
             # parameters live on the default stream, part of the graph now runs on another one: the engine's stream
             # hand-over is intended
@@ -790,11 +793,12 @@ class Trainer():
         # step's copy, which completes while this step's launches are already queued -- the queue never drains at a step
         # boundary (profiles/r02_step_timeline.txt: 0.69 + 0.47 ms idle per boundary with the blocking read-back).
         if ddp.is_dist():
+            # ONE small collective per step: the six statistics are averaged, the NaN flag is summed (any rank -> > 0), so
+            # every rank raises / recovers together
             nan_flag = torch.isnan(stats[:4]).any().double().reshape(1)
-            packed = torch.cat([stats, nan_flag])
-            torch.distributed.all_reduce(packed[:6], op=torch.distributed.ReduceOp.SUM)
-            torch.distributed.all_reduce(packed[6:], op=torch.distributed.ReduceOp.MAX)
-            packed[:6] /= ddp.world_size()
+            packed = torch.cat([stats, nan_flag * ddp.world_size()])
+            torch.distributed.all_reduce(packed, op=torch.distributed.ReduceOp.SUM)
+            packed /= ddp.world_size()
         else:
             packed = torch.cat([stats, torch.zeros(1, dtype=stats.dtype, device=stats.device)])
         host = self._host_buffer()
@@ -871,6 +875,19 @@ class Trainer():
                     self._raise_nan(meta['checkpoint'])
                 self._nan_checkpoint = meta['checkpoint']
                 return
+
+    def flush(self):
+        """Consume every pending read-back NOW and apply the reference's NaN handling (:1002-1010) to what it finds: restore
+        the last checkpoint and raise NanException.  The deferred read-back looks at step n's statistics inside the
+        train() call of step n + 1; the LAST step of a run has no successor, so call this after a training loop and before
+        weights leave the process -- `save()` does it itself (a NaN step is never written), `evaluate()` and `print_log()`
+        read the statistics and thereby arm the same exception for the next `train()` / `flush()` / `save()`."""
+        if self._pending:
+            self._drain(0, in_train=False)
+        if self._nan_checkpoint is not None:
+            self._raise_nan(self._nan_checkpoint)
+
+    finalize = flush
 
     def _raise_nan(self, checkpoint_num):
         # save from NaN errors (reference :1002-1010)
@@ -968,6 +985,7 @@ class Trainer():
         self.init_folders()
 
     def save(self, num):
+        self.flush()           # never persist the weights of a step whose NaN check is still pending (raises NanException)
         if self.is_main:       # rank 0 alone writes (replicas are identical)
             torch.save(self.GAN.state_dict(), self.model_name(num))
             self.write_config()

@@ -136,6 +136,25 @@ def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hi
     return out
 
 
+def oracle_d_phase_fakes(sd0, batch, rng, L):
+    """The generator output the D phase of `oracle_train_step` scores (reference :899-903), evaluated with `rng`'s dtype on
+    its device -- consumes the same draws (two latents, one image noise) as the step's D phase.  Used to pick latents whose
+    fakes keep every discriminator pre-activation clear of zero (lrelu_margin), as the real images are picked."""
+    from oracle import histogan_nets as N
+    dev, dt = rng.dev, rng.dtype
+    cvt = lambda t: t.detach().to(dev).to(dt)
+    sub = lambda p: {k[len(p) + 1:]: cvt(v) for k, v in sd0.items() if k.startswith(p + '.') and v.dtype.is_floating_point}
+    sG, sS, sH = sub('G'), sub('S'), sub('H')
+    B = batch['images'].shape[0]
+    LAT = sG['blocks.0.to_style1.weight'].shape[1]
+    with torch.no_grad():
+        style = rng.mixed_list(B, L - 2, LAT)
+        noise = rng.image_noise(B, batch['images'].shape[-1])
+        w = [(N.vectorizer(sS, z, 'net'), n) for z, n in style]
+        hw = N.vectorizer(sH, cvt(batch['histograms']), 'fcs')[:, None, :]
+        return N.generator(sG, N.styles_def_to_tensor(w), torch.cat((hw, hw), 1), noise, L)
+
+
 def lrelu_margin(sd_d, images, nblk):
     """Smallest |pre-activation| of any LeakyReLU of the discriminator on `images`, relative to its layer's largest, evaluated
     in fp64.  A pre-activation within fp32 rounding of zero (~1e-7 relative) gets the other LeakyReLU slope in ANY fp32

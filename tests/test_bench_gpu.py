@@ -54,3 +54,21 @@ def test_bench_train_stdout_is_one_json_line_under_graph_replay(gpu_device):
     out = _bench({'HG_GRAPH': '1'}, '--gpus', '1', '--steps', '12', '--warmup', '2', '--batch', '4', '--no-roofline',
                  '--no-cpu-baseline', '--no-reference-eager')
     assert out['graph_replayed_steps'] > 0 and out['value'] > 0
+
+
+def test_bench_gpus_2_launches_two_ranks_itself(gpu_device):
+    """`python bench.py --gpus 2` with NO launcher environment must start two ranks itself (round 3's
+    --gpus was decorative).  Two gloo ranks share GPU 0 here; on a multi-GPU node the same path puts one rank per device
+    on RCCL (asserted by the launcher before it starts anything and by the `ddp` self-check)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+    env.update(HG_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '1',
+                        '--batch', '4', '--size', '64', '--capacity', '4', '--bins', '16', '--no-roofline'],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['ddp']['backend'] == 'gloo'
+    assert [rk['rank'] for rk in out['ddp']['ranks']] == [0, 1] and all(rk['world_size'] == 2 for rk in out['ddp']['ranks'])
+    assert out['config']['global_batch'] == 8 and out['value'] > 0

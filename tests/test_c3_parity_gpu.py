@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import ROOT, relmax
-from oracle_step import ReplayRng, lrelu_margin, oracle_train_step
+from oracle_step import ReplayRng, lrelu_margin, oracle_d_phase_fakes, oracle_train_step
 
 pytestmark = pytest.mark.gpu
 
@@ -213,7 +213,7 @@ def test_c3_discriminator_and_gradient_penalty_match_fp64_oracle(gpu_device):
 
 
 # ---- (c) + (d) one train step at 256^2 / capacity 16 -----------------------------------------------------------------
-@pytest.mark.parametrize('step_no', [1, 4, 0], ids=['plain', 'gradient-penalty', 'gp+path-length'])
+@pytest.mark.parametrize('step_no', [1, 4, 0], ids=['plain-active-hinge', 'gradient-penalty', 'gp+path-length'])
 def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
     """Trainer.train() at 256^2, capacity 16, h = 64, trainer-default histogram (256 -> 150 bilinear), B = 2: a plain
     step (one [fake; real] discriminator pass), a gradient-penalty step and step 0 (penalty + path-length term), against the oracle step in fp64 (truth) and
@@ -230,12 +230,18 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
     tr.run_evaluate = tr.run_save = False
     tr.init_GAN()
     GAN = tr.GAN
+    gp, pl = step_no % 4 == 0, step_no % 32 == 0
     with torch.no_grad():
         for blk in GAN.G.blocks:
             blk.to_noise1.weight.normal_(std=0.3); blk.to_noise2.weight.normal_(std=0.3)
+        if not gp:
+            # The plain step's D phase (one [fake; real] pass, reference :889-932) must be compared with NON-ZERO gradients: at
+            # the kaiming initialisation |logit| ~ 300, so relu(1 + real) = relu(1 - fake) = 0 and every discriminator gradient
+            # is exactly 0 (round 3's record: d_loss 0.0).  A small logit layer puts every sample inside the hinge.
+            GAN.D.to_logit.weight.mul_(1e-3)
+            GAN.D.to_logit.bias.zero_()
     L = GAN.G.num_layers
     sd0 = {k: v.detach().clone() for k, v in GAN.state_dict().items()}
-    gp, pl = step_no % 4 == 0, step_no % 32 == 0
     # real images whose LeakyReLU pre-activations all stay clear of zero in fp64 (oracle_step.lrelu_margin): with the first
     # candidate seed one of the 7.9e6 pre-activations is 1.3e-9 of its layer's maximum, and every fp32 evaluation takes
     # the other slope there than fp64 -- a 1e-2 difference in one weight gradient of the penalty's second-order terms
@@ -250,11 +256,20 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
             hist = OH.rgbuv_hist(torch.rand(B, 3, S_, S_, generator=gen), h=HB)
             batches.append({'images': img.to(dev), 'histograms': hist.to(dev)})
         margin = lrelu_margin(sd_d, batches[0]['images'], L + 1)
-        if not gp or margin > 5e-8:
+        if margin > 5e-8:
             break
-    assert not gp or margin > 5e-8, margin
+    assert margin > 5e-8, margin
+    # ... and, on the plain step (where the fakes' half of the hinge carries gradients into D), latents whose fakes do too
+    rng_seed, fake_margin = 78, None
+    if not gp:
+        for rng_seed in range(78, 118):
+            fakes = oracle_d_phase_fakes(sd0, batches[0], ReplayRng(dev, B, L, LAT, S_, rng_seed, tt=2, dtype=torch.float64), L)
+            fake_margin = lrelu_margin(sd_d, fakes, L + 1)
+            if fake_margin > 5e-8:
+                break
+        assert fake_margin > 5e-8, fake_margin
     tr.loader = iter(batches)
-    tr.rng = ReplayRng(dev, B, L, LAT, S_, 78, tt=2)
+    tr.rng = ReplayRng(dev, B, L, LAT, S_, rng_seed, tt=2)
     tr.steps = step_no
     tr.train(alpha=ALPHA)
     new = {k: v.detach() for k, v in GAN.state_dict().items()}
@@ -262,15 +277,19 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
     # the G phase of both oracle runs scores the fakes with the discriminator the product path used (see oracle_step.py:
     # the first DiffGrad step is sign-like, its result ill-conditioned wherever a gradient is rounding noise)
     d_used = {k[2:]: v for k, v in new.items() if k.startswith('D.')}
-    truth = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, 78, tt=2, dtype=torch.float64), L, HB, ALPHA,
+    truth = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, rng_seed, tt=2, dtype=torch.float64), L, HB, ALPHA,
                               LR, gp, pl, d_override=d_used)
-    ref32 = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, 78, tt=2), L, HB, ALPHA, LR, gp, pl,
+    ref32 = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, rng_seed, tt=2), L, HB, ALPHA, LR, gp, pl,
                               d_override=d_used)
     rel = lambda a, b: abs(a - b) / max(1.0, abs(b))      # the un-normalised logits are >> 1 at this capacity
-    rec = dict(data_seed=data_seed, lrelu_margin=margin, d_loss=rel(tr.d_loss, truth['d_loss']), g_loss=rel(tr.g_loss, truth['g_loss']),
+    rec = dict(data_seed=data_seed, lrelu_margin=margin, rng_seed=rng_seed, lrelu_margin_fakes=fake_margin, d_loss=rel(tr.d_loss, truth['d_loss']), g_loss=rel(tr.g_loss, truth['g_loss']),
                h_loss=abs(tr.h_loss - truth['h_loss']), values=dict(d=truth['d_loss'], g=truth['g_loss'], h=truth['h_loss']),
                g_loss_ref32=rel(ref32['g_loss'], truth['g_loss']))
     assert rec['d_loss'] <= 1e-4 and rec['g_loss'] <= 1e-4 and rec['h_loss'] <= 1e-4, rec
+    if not gp:
+        # non-vacuous: both hinge terms active, every discriminator tensor has a gradient
+        assert truth['d_loss'] > 0.1, truth['d_loss']
+        assert all(float(t.abs().max()) > 0 for pk, t in truth['grads'].items() if pk[0] == 'D' and pk[1].endswith('weight'))
     if gp:
         rec['gp'] = rel(tr.last_gp_loss, truth['gp'])
         rec['values']['gp'] = truth['gp']
@@ -280,17 +299,27 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
     # gradient-penalty steps they are the penalty's second-order terms through the LeakyReLU masks (the data above keeps
     # every pre-activation clear of zero, so fp32 and fp64 evaluations take the same slopes): 1e-4 per tensor.
     worst_d, off, od, rd = (-1.0, ''), 0, [], []
+    # (with every sample inside the hinge the logit gradients are +1/2B on the real and -1/2B on the fake half: they sum to
+    # zero, so the gradients of to_logit.bias and of the last block's conv_res.bias -- linear paths into the logit -- vanish
+    # identically in exact arithmetic; such a tensor is held to the scale of the other bias gradients instead of its own)
+    bias_scale = max(float(t.abs().max()) for pk, t in truth['grads'].items() if pk[0] == 'D' and pk[1].endswith('bias'))
+    def rel_d(a, t, name):
+        a, t = a.double(), t.double()
+        den = float(t.abs().max())
+        if name.endswith('bias'):
+            den = max(den, 1e-3 * bias_scale)
+        return float((a - t).abs().max()) / max(den, 1e-300)
     for prm in GAN._flat_d.params:
         n = prm.numel()
         name = next(k for k, v in GAN.D.named_parameters() if v is prm)
         mine = GAN._flat_d.grad[off:off + n].view(prm.shape)
         t = truth['grads'][('D', name)]
-        worst_d = max(worst_d, (_rel(mine, t), name), key=lambda v: v[0])
+        worst_d = max(worst_d, (rel_d(mine, t, name), name), key=lambda v: v[0])
         od.append((mine.double() - t).flatten()); rd.append((ref32['grads'][('D', name)].double() - t).flatten())
         off += n
     tnd = torch.cat([t.flatten() for pk, t in truth['grads'].items() if pk[0] == 'D']).norm().clamp_min(1e-300)
     rec['d_grad_worst_ours'], rec['d_grad_worst_name'] = worst_d
-    rec['d_grad_worst_ref32'] = max(_rel(ref32['grads'][pk], t) for pk, t in truth['grads'].items() if pk[0] == 'D')
+    rec['d_grad_worst_ref32'] = max(rel_d(ref32['grads'][pk], t, pk[1]) for pk, t in truth['grads'].items() if pk[0] == 'D')
     rec['d_grad_rms_ours'], rec['d_grad_rms_ref32'] = float(torch.cat(od).norm() / tnd), float(torch.cat(rd).norm() / tnd)
     _record(f'train_step/{"gp+pl" if pl else "gp" if gp else "plain"}', rec)
     assert worst_d[0] <= max(1e-4, 2 * rec['d_grad_worst_ref32']), rec
@@ -318,9 +347,88 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
     for (p, k), t in truth['params'].items():
         gr = truth['grads'][(p, k)]
         mask = gr.abs() > 5e-2 * gr.abs().max()
-        if not bool(mask.any()):          # an exactly zero gradient (inactive hinge at this init): no update either way
+        if p == 'D' and k.endswith('bias') and float(gr.abs().max()) < 1e-3 * bias_scale:
+            continue                      # a structurally zero gradient (see above): the update's sign is rounding noise
+        if not bool(mask.any()):          # an exactly zero gradient: no update either way
             assert torch.equal(new[f'{p}.{k}'], sd0[f'{p}.{k}']), (p, k)
             continue
         dn = (new[f'{p}.{k}'].double() - sd0[f'{p}.{k}'].double())
         do = (t - sd0[f'{p}.{k}'].double())
         assert float((dn - do).abs()[mask].max()) <= 0.02 * LR, (p, k)
+
+
+# ---- (e) the HIP networks against goldens of the UNMODIFIED reference at this width --------------------------------------
+def test_c3_networks_match_reference_golden(gpu_device):
+    """tests/golden/nets_c3.npz: the reference's own Generator(256, 512, 16) / Discriminator(256, 16) / gradient_penalty
+    (histoGAN/histoGAN.py:529-631, 156-163) run on the CPU at B = 1 with seeded weights (make_golden_nets_c3.py; the same
+    file pins the oracle in tests/test_oracle_nets_c3_golden.py).  rgb / logits 1e-5, penalty and loss 1e-4, gradients 1e-4:
+    every small tensor in full, every tensor through its signed-sum / L2-norm reductions."""
+    import importlib.util
+    from conftest import GOLDEN_DIR
+    from histoGAN import Discriminator, Generator
+    from histoGAN.histoGAN import gradient_penalty
+    spec = importlib.util.spec_from_file_location('make_golden_nets_c3', os.path.join(GOLDEN_DIR, 'make_golden_nets_c3.py'))
+    mk = importlib.util.module_from_spec(spec); spec.loader.exec_module(mk)
+    z = np.load(os.path.join(GOLDEN_DIR, 'nets_c3.npz'))
+    g = {k: z[k] for k in z.files}
+    specs, seed = json.loads(str(g['spec'])), int(g['meta'][5])
+    S2, CAP2, LAT2, B, L, _ = [int(v) for v in g['meta']]
+    assert (S2, CAP2, LAT2) == (S_, CAP, LAT)
+    dev = gpu_device
+    gen = torch.Generator(device='cpu').manual_seed(seed + 2)
+    styles = torch.randn(B, L - 2, LAT, generator=gen).to(dev).requires_grad_(True)
+    hists = torch.randn(B, 2, LAT, generator=gen).to(dev).requires_grad_(True)
+    noise = torch.rand(B, S_, S_, 1, generator=gen).to(dev)
+    go = torch.randn(B, 3, S_, S_, generator=gen).to(dev)
+    img = torch.rand(B, 3, S_, S_, generator=gen).to(dev)
+    rec = {}
+
+    def check_grads(prefix, names, grads, seed0):
+        worst_full, worst_red = (0.0, ''), (0.0, '')
+        for i, (n, gr) in enumerate(zip(names, grads)):
+            red = mk.reductions(gr.cpu(), seed + seed0 + i)
+            ref = g[f'{prefix}_red/{n}']
+            e = max(abs(red[0] - ref[0]), abs(red[1] - ref[1])) / max(ref[1], 1e-30)
+            worst_red = max(worst_red, (e, n))
+            if f'{prefix}_grad/{n}' in g:
+                worst_full = max(worst_full, (relmax(gr.cpu().numpy(), g[f'{prefix}_grad/{n}']), n))
+        return worst_full, worst_red
+
+    G = Generator(S_, LAT, network_capacity=CAP).to(dev)
+    sd = mk.synth_state_dict(specs['G'], seed)
+    assert np.array_equal(mk.fingerprint(sd), g['G_fingerprint'])
+    G.load_state_dict(sd, strict=True)
+    from histogan_amd.conv import weights_changed
+    weights_changed()
+    rgb = G(styles, hists, noise)
+    names = [n for n, _ in G.named_parameters()]
+    params = dict(G.named_parameters())
+    grads = torch.autograd.grad(rgb, [styles, hists] + [params[n] for n in names], go)
+    rec['rgb'] = relmax(rgb.detach().cpu().numpy(), g['g_rgb'])
+    rec['g_styles'] = relmax(grads[0].cpu().numpy(), g['g_grad_styles'])
+    rec['g_hists'] = relmax(grads[1].cpu().numpy(), g['g_grad_hists'])
+    rec['g_full'], rec['g_red'] = check_grads('g', names, grads[2:], 100)
+    del G, grads, rgb
+
+    D = Discriminator(S_, network_capacity=CAP).to(dev)
+    sd = mk.synth_state_dict(specs['D'], seed + 1)
+    assert np.array_equal(mk.fingerprint(sd), g['D_fingerprint'])
+    D.load_state_dict(sd, strict=True)
+    weights_changed()
+    x = img.clone().requires_grad_(True)
+    logits, _ = D(x)
+    gp = gradient_penalty(x, logits.reshape(B))
+    loss = torch.relu(1 + logits).mean() + gp
+    dnames = [n for n, _ in D.named_parameters()]
+    dparams = dict(D.named_parameters())
+    dgr = torch.autograd.grad(loss, [dparams[n] for n in dnames])
+    rec['logits'] = relmax(logits.detach().cpu().numpy().reshape(-1), g['d_logits'])
+    rec['gp'] = abs(float(gp) - float(g['d_gp'])) / max(1.0, abs(float(g['d_gp'])))
+    rec['d_loss'] = abs(float(loss) - float(g['d_loss'])) / max(1.0, abs(float(g['d_loss'])))
+    rec['d_full'], rec['d_red'] = check_grads('d', dnames, dgr, 500)
+    _record('reference_golden_c3', rec)
+    assert rec['rgb'] <= 1e-5 and rec['logits'] <= 1e-5, rec
+    assert rec['gp'] <= 1e-4 and rec['d_loss'] <= 1e-4, rec
+    assert rec['g_styles'] <= 1e-4 and rec['g_hists'] <= 1e-4, rec
+    assert rec['g_full'][0] <= 1e-4 and rec['g_red'][0] <= 1e-4, rec
+    assert rec['d_full'][0] <= 1e-4 and rec['d_red'][0] <= 1e-4, rec

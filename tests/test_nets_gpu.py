@@ -229,6 +229,75 @@ def test_train_step_matches_oracle(gpu_device, tmp_path):
         assert np.max(np.abs(dn - do)[mask]) <= 0.02 * LR, (p, k)
 
 
+def test_plain_step_d_phase_matches_oracle(gpu_device, tmp_path):
+    """Step 1 -- a PLAIN step: no gradient penalty, ONE discriminator pass over [fake; real] (trainer._cat_batches, the
+    fused LeakyReLU-backward / bias-gradient path at twice the batch) -- against the oracle's two-pass D phase
+    (reference histoGAN/histoGAN.py:889-932) on the CPU in fp64 / fp32, with the hinge ACTIVE on both halves: the logit
+    layer is scaled down so that |logit| < 1 (at the kaiming initialisation relu(1 + real) = relu(1 - fake) = 0 for most
+    samples and the D gradients would be compared as 0 == 0).  Discriminator gradients 1e-4 per tensor, loss 1e-4,
+    masked parameter deltas after DiffGrad."""
+    from histoGAN import Trainer
+    from oracle import rgbuv_hist as OH
+    from oracle_step import ReplayRng, oracle_train_step
+    torch.manual_seed(12)
+    S_, CAP, B, HB, ALPHA, LR = 32, 4, 4, 16, 2.0, 2e-4
+    tr = Trainer('t', tmp_path / 'r', tmp_path / 'm', S_, CAP, batch_size=B, lr=LR, hist_bin=HB, hist_insz=150,
+                 hist_resizing='interpolation', mixed_prob=1.1)
+    tr.run_evaluate = tr.run_save = False
+    tr.graph_mode = '0'
+    tr.init_GAN()
+    GAN = tr.GAN
+    with torch.no_grad():
+        for blk in GAN.G.blocks:
+            blk.to_noise1.weight.normal_(std=0.3); blk.to_noise2.weight.normal_(std=0.3)
+        GAN.D.to_logit.weight.mul_(2e-3); GAN.D.to_logit.bias.zero_()
+    L, LAT = GAN.G.num_layers, GAN.G.latent_dim
+    sd0 = {k: v.detach().cpu().clone() for k, v in GAN.state_dict().items()}
+    gen = torch.Generator().manual_seed(6)
+    batches = []
+    for _ in range(2):
+        img = torch.rand(B, 3, S_, S_, generator=gen)
+        hist = OH.rgbuv_hist(torch.rand(B, 3, S_, S_, generator=gen), h=HB)
+        batches.append({'images': img, 'histograms': hist})
+    tr.loader = iter([{k: v.to(gpu_device) for k, v in b.items()} for b in batches])
+    tr.rng = ReplayRng(gpu_device, B, L, LAT, S_, 79)
+    tr.steps = 1
+    tr.train(alpha=ALPHA)
+    new = {k: v.detach().cpu() for k, v in GAN.state_dict().items()}
+    cpu = torch.device('cpu')
+    ref = oracle_train_step(sd0, batches, ReplayRng(cpu, B, L, LAT, S_, 79), L, HB, ALPHA, LR, False, False)
+    truth = oracle_train_step(sd0, batches, ReplayRng(cpu, B, L, LAT, S_, 79, dtype=torch.float64), L, HB, ALPHA, LR,
+                              False, False)
+    assert truth['d_loss'] > 0.1, truth['d_loss']            # non-vacuous
+    assert abs(tr.d_loss - truth['d_loss']) <= 1e-4
+    off = 0
+    bias_scale = max(float(t.abs().max()) for pk, t in truth['grads'].items() if pk[0] == 'D' and pk[1].endswith('bias'))
+    for prm in GAN._flat_d.params:          # the D phase's gradients are still in D's flat gradient buffer
+        n = prm.numel()
+        name = next(k for k, v in GAN.D.named_parameters() if v is prm)
+        mine = GAN._flat_d.grad[off:off + n].view(prm.shape).detach().cpu().double()
+        t = truth['grads'][('D', name)]
+        # (every sample inside the hinge: the logit gradients +-1/2B sum to zero, so to_logit.bias and the last block's
+        # conv_res.bias -- linear paths into the logit -- have identically zero gradients; held to the other biases' scale)
+        den = float(t.abs().max())
+        if name.endswith('bias'):
+            den = max(den, 1e-3 * bias_scale)
+        else:
+            assert den > 0, name
+        e_o = float((mine - t).abs().max()) / den
+        e_r = float((ref['grads'][('D', name)].double() - t).abs().max()) / den
+        assert e_o <= max(1e-4, 3 * e_r), (name, e_o, e_r)
+        off += n
+    for k, v in truth['params_d'].items():
+        gr = truth['grads'][('D', k)].numpy()
+        if k.endswith('bias') and np.abs(gr).max() < 1e-3 * bias_scale:
+            continue
+        mask = np.abs(gr) > 5e-2 * np.abs(gr).max()
+        dn = (new[f'D.{k}'].double() - sd0[f'D.{k}'].double()).numpy()
+        do = (v - sd0[f'D.{k}'].double()).numpy()
+        assert np.max(np.abs(dn - do)[mask]) <= 0.02 * LR, k
+
+
 @pytest.mark.parametrize('shape', [(3, 5, 4, 4), (2, 16, 64, 64), (7, 3, 5, 9), (1, 1, 1, 1), (4, 130, 8, 8)])
 def test_channel_sum_matches_torch(shape, gpu_device):
     from histogan_amd import ops

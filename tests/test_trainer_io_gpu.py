@@ -109,6 +109,36 @@ def test_nan_recovery_raises_nanexception(lazy, gpu_device, tmp_path):
     del good
 
 
+def test_trailing_nan_step_is_caught_by_flush_and_never_saved(gpu_device, tmp_path):
+    """with the deferred read-back the LAST step of a run has no following train() call to look at its
+    statistics.  Trainer.flush() (alias finalize()) drains them and applies the reference's NaN handling (:1002-1010);
+    save() calls it first, so a direct save after the loop cannot persist NaN weights."""
+    from histoGAN import NanException, Trainer
+    from histogan_amd.conv import weights_changed
+    tr = Trainer('nanlast', str(tmp_path / 'r'), str(tmp_path / 'm'), 32, 2, batch_size=2, hist_bin=16, hist_insz=32,
+                 hist_resizing='interpolation', save_every=1000)
+    tr.run_evaluate = False
+    assert tr.lazy_stats
+    tr.set_synthetic_data_src()
+    tr.train(alpha=2)                                    # step 0 writes checkpoint 0
+    with torch.no_grad():
+        tr.GAN.D.to_logit.weight.fill_(float('nan'))
+    weights_changed()
+    tr.train(alpha=2)                                    # the run's last step: NaN, statistics still in flight
+    with pytest.raises(NanException):
+        tr.save(5)                                       # direct save after the loop: flushes, restores, raises
+    assert not (tmp_path / 'm' / 'nanlast' / 'model_5.pt').exists()
+    assert all(torch.isfinite(v).all() for v in tr.GAN.state_dict().values()) and tr.steps == 0
+    tr.flush()                                           # nothing pending any more: no-op
+    tr.train(alpha=2)
+    with torch.no_grad():
+        tr.GAN.D.to_logit.weight.fill_(float('nan'))
+    weights_changed()
+    tr.train(alpha=2)
+    with pytest.raises(NanException):
+        tr.finalize()
+
+
 def test_gradient_accumulation_steps(gpu_device, tmp_path):
     """gradient_accumulate_every = 2 with mixed_prob = 0 (reference :889-932: losses divided by the count, gradients
     accumulated over the micro-batches before one optimizer step)."""
