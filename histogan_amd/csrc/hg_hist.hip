@@ -41,6 +41,9 @@
 #ifndef HG_FWD_PACKED
 #define HG_FWD_PACKED 1   // packed-fp32 (v_pk_*) operand generation in k_hist_fwd
 #endif
+#ifndef HG_FWD_SHARE_ASM
+#define HG_FWD_SHARE_ASM 1   // shared-reciprocal operand generation of k_hist_fwd as one block of packed instructions
+#endif
 #ifndef HG_FWD_MFMA_GROUP
 #define HG_FWD_MFMA_GROUP 12  // k_hist_fwd at configs[1]: groups of 1: 505 us, 3: 498, 6: 473, 12: 465
 #endif
@@ -54,9 +57,24 @@
 #define HG_BWD_WAVES 2  // min waves/SIMD the backward kernel is register-budgeted for
 #endif
 
+#ifndef HG_HIST_PROBE
+#define HG_HIST_PROBE 0      // 1 (tagged experiment builds only): per-phase shader-cycle counters in k_hist_fwd / k_hist_bwd
+#endif
+
 namespace {
 
+#if HG_HIST_PROBE
+// [kernel 0 fwd / 1 bwd][0 waves, 1 total, 2 prologue, 3 projection / pixel state, 4 K loops, 5 epilogue, 6 longest wave, 7 spare]
+__device__ unsigned long long hg_probe[2][8];
+#define HG_PROBE_T(var) const long long var = __builtin_readcyclecounter()
+#else
+#define HG_PROBE_T(var)
+#endif
+
 constexpr float kEps = 1e-6f;  // RGBuvHistBlock.py:26
+// k_hist_fwd's per-wave staging row: 64 pixels + 4 entries of slack -- the K loop prefetches the (a, b, c, weight) tuple two
+// steps ahead without clamping the index (the operands made from entries past the batch are never multiplied)
+constexpr int kFwdStage = 68;
 
 struct DevParams {
   int B, C, H, W;
@@ -214,22 +232,28 @@ __device__ __forceinline__ void lds_wave_sync() {
 // Each wave owns a contiguous run of `chunk` pixels and accumulates a (3 x BLK x BLK) partial
 // histogram block (BLK = 32*T) in 3*T*T MFMA accumulator tiles; the 4 waves are then summed through
 // LDS in fixed order and written as one slab  slabs[b][s][p][h][h]  (real bin order, flips undone).
-template <int T, int METHOD, bool SYM, bool DIAG, bool GREEN>
+template <int T, int METHOD, bool SYM, bool DIAG, bool GREEN, bool SHARE = false>
 __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const float *__restrict__ x,
                                                      float *__restrict__ slabs, double *__restrict__ slab_tot,
                                                      const int chunk) {
   constexpr int BLK = 32 * T;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float4 *stage = reinterpret_cast<float4 *>(smem);            // [4 waves][64 pixels]
-  float *red = reinterpret_cast<float *>(smem + 4 * 64 * 16);  // [3][BLK][BLK]
+  float4 *stage = reinterpret_cast<float4 *>(smem);            // [4 waves][kFwdStage pixels]
+  float *red = reinterpret_cast<float *>(smem + 4 * kFwdStage * 16);  // [3][BLK][BLK]
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // wave-uniform values in scalar registers: loop bounds and addresses derived from them cost no VALU issue slots
+  // (which the MFMAs of this kernel pay for)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int half = lane >> 5, l31 = lane & 31;
   const int nbd = (P.h + BLK - 1) / BLK;
   const int bi = blockIdx.y / nbd, bj = blockIdx.y - bi * nbd;
   const int b = blockIdx.z, s = blockIdx.x, S = gridDim.x;
   const float *xb = x + (long long)b * P.sb;
 
+  HG_PROBE_T(pt0);
+#if HG_HIST_PROBE
+  long long p_proj = 0, p_loop = 0;
+#endif
   // per-lane bin constants: A side = rows (i) of this block, B side = columns (j)
   BinC cA[T], cAm[T], cB[T], cBm[T];
 #pragma unroll
@@ -272,7 +296,70 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
     const f32x2 den = __builtin_elementwise_fma(t, t, one);
     return f32x2{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
   };
-  auto make_ops = [&](const float4 &q, Ops<T> &o) {
+  // denominators 1 + t^2 of the two tiles of one variable (no reciprocal yet)
+  auto den2 = [&](float u, const f32x2 &chi, const f32x2 &clo) __attribute__((always_inline)) -> f32x2 {
+    const f32x2 uu = {u, u}, is = {P.inv_sigma, P.inv_sigma}, one = {1.f, 1.f};
+    const f32x2 t = __builtin_elementwise_fma(uu, is, chi) + clo;
+    return __builtin_elementwise_fma(t, t, one);
+  };
+  auto make_ops = [&](const f32x4 &q, Ops<T> &o) {
+    if constexpr (SHARE) {
+      // Shared reciprocals (round 4; PMC: profiles/r04_hist_pmc_stalls.txt).  fp32 MFMA and VALU instructions share
+      // the issue path on gfx950, and v_rcp_f32 runs at a quarter of the VALU rate: the six reciprocals of a K step were
+      // 96 of its ~1 035 cycles.  1/a and 1/b from ONE reciprocal: r = 1/(a b), 1/a = b r, 1/b = a r -- here for the four
+      // denominators of (ka, kb) at once (r = 1/(a0 b0 a1 b1)) and the two of kc: 2 v_rcp + 7 packed multiplies instead
+      // of 6 v_rcp + 2.  Each value picks up ~3 roundings instead of 1 (<= 2e-7 relative; the parity bars are 1e-5).
+      // The launcher takes this instantiation only when (1 + t_max^2)^4 stays far below the fp32 range.
+      static_assert(T == 2 && METHOD == HG_METHOD_INVERSE_QUADRATIC && SYM && DIAG && !GREEN, "shared-reciprocal path");
+#if HG_FWD_SHARE_ASM
+      // Written as ONE block of packed instructions: clang 22 "unpacks" v_pk_* instructions that follow an MFMA into two
+      // scalar ones (a peephole meant for the 16-bit MFMAs, whose shadow hides VALU work) -- on the fp32 MFMA, which
+      // shares the fp32 lanes with the VALU, that doubles their cost.  20 VALU instructions + 2 v_rcp_f32 per K step;
+      // v[244:255] are the block's temporaries.  s_nop 0: trans result -> next VALU read; s_nop 1: VALU write -> MFMA read.
+      const f32x2 qxy = __builtin_shufflevector(q, q, 0, 1), qzw = __builtin_shufflevector(q, q, 2, 3);
+      const f32x2 is2 = {P.inv_sigma, P.inv_sigma};
+      f32x2 a0, a2, b0, b1;
+      asm volatile(
+          "v_pk_fma_f32 v[244:245], %4, %6, %7 op_sel_hi:[0,1,1]\n\t"                    // t(a) = a / sigma + c_hi
+          "v_pk_fma_f32 v[246:247], %4, %6, %9 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"     // t(b)
+          "v_pk_fma_f32 v[248:249], %5, %6, %11 op_sel_hi:[0,1,1]\n\t"                   // t(c)
+          "v_pk_add_f32 v[244:245], v[244:245], %8\n\t"                                   // + c_lo
+          "v_pk_add_f32 v[246:247], v[246:247], %10\n\t"
+          "v_pk_add_f32 v[248:249], v[248:249], %12\n\t"
+          "v_pk_fma_f32 v[244:245], v[244:245], v[244:245], 1.0 op_sel_hi:[1,1,0]\n\t"   // da = 1 + t^2
+          "v_pk_fma_f32 v[246:247], v[246:247], v[246:247], 1.0 op_sel_hi:[1,1,0]\n\t"   // db
+          "v_pk_fma_f32 v[248:249], v[248:249], v[248:249], 1.0 op_sel_hi:[1,1,0]\n\t"   // dc
+          "v_pk_mul_f32 v[250:251], v[244:245], v[246:247]\n\t"                           // (a0 b0, a1 b1)
+          "v_mul_f32 v253, v248, v249\n\t"                                                // c0 c1
+          "v_mul_f32 v252, v250, v251\n\t"                                                // a0 b0 a1 b1
+          "v_rcp_f32 v253, v253\n\t"
+          "v_rcp_f32 v252, v252\n\t"
+          "s_nop 0\n\t"
+          "v_pk_mul_f32 %3, v[248:249], v[252:253] op_sel:[1,1] op_sel_hi:[0,1]\n\t"      // kc = (c1, c0) / (c0 c1)
+          "v_pk_mul_f32 v[250:251], v[250:251], v[252:253] op_sel:[1,0] op_sel_hi:[0,0]\n\t"  // (1/(a0 b0), 1/(a1 b1))
+          "v_pk_mul_f32 v[254:255], v[250:251], %5 op_sel:[0,1] op_sel_hi:[1,1]\n\t"      // ... times the weight
+          "v_pk_mul_f32 %2, v[244:245], v[250:251]\n\t"                                   // kb = da / (da db)
+          "v_pk_mul_f32 %0, v[246:247], v[254:255]\n\t"                                   // w ka
+          "v_pk_mul_f32 %1, v[244:245], v[254:255]\n\t"                                   // w kb
+          "s_nop 1"
+          : "=&v"(a0), "=&v"(a2), "=&v"(b0), "=&v"(b1)
+          : "v"(qxy), "v"(qzw), "s"(is2), "v"(chiA), "v"(cloA), "v"(chiAm), "v"(cloAm), "v"(chiB), "v"(cloB)
+          : "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+#else
+      const f32x2 da = den2(q.x, chiA, cloA), db = den2(q.y, chiAm, cloAm), dc = den2(q.z, chiB, cloB);
+      const f32x2 pab = da * db;                                    // (a0 b0, a1 b1)
+      const float r4 = __builtin_amdgcn_rcpf(pab.x * pab.y);
+      const f32x2 rab = f32x2{pab.y, pab.x} * f32x2{r4, r4};        // (1/(a0 b0), 1/(a1 b1))
+      const f32x2 wr = rab * f32x2{q.w, q.w};
+      const f32x2 a0 = db * wr, a2 = da * wr;                       // w ka, w kb
+      const f32x2 b0 = da * rab;                                    // kb
+      const float r2 = __builtin_amdgcn_rcpf(dc.x * dc.y);
+      const f32x2 b1 = f32x2{dc.y, dc.x} * f32x2{r2, r2};           // kc
+#endif
+      o.A0[0] = a0.x; o.A0[1] = a0.y; o.A1[0] = a0.x; o.A1[1] = a0.y; o.A2[0] = a2.x; o.A2[1] = a2.y;
+      o.B0[0] = b0.x; o.B0[1] = b0.y; o.B1[0] = b1.x; o.B1[1] = b1.y; o.B2[0] = b1.x; o.B2[1] = b1.y;
+      return;
+    }
     if constexpr (T == 2 && METHOD == HG_METHOD_INVERSE_QUADRATIC && HG_FWD_PACKED) {
       const f32x2 w2 = {q.w, q.w};
       const f32x2 ka = iq2(q.x, chiA, cloA), kbA = iq2(q.y, chiAm, cloAm);
@@ -303,11 +390,13 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
   // the pre-pass cost 23 us.  The other wave of the SIMD evidently hides most of it here; it stays in the kernel.)
   float r_ = 0.f, g_ = 0.f, b_ = 0.f;
   if (start + lane < end) sample_rgb(P, xb, (int)start + lane, r_, g_, b_);
+  HG_PROBE_T(pt1);
   for (int base = (int)start; base < end; base += 64) {
+    HG_PROBE_T(pb0);
     float a, bb, c, iy;
     project(P, r_, g_, b_, a, bb, c, iy);
     const bool valid = base + lane < end;
-    stage[wave * 64 + lane] = valid ? make_float4(a, bb, c, iy) : make_float4(0.f, 0.f, 0.f, 0.f);
+    stage[wave * kFwdStage + lane] = valid ? make_float4(a, bb, c, iy) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (P.cache && valid && blockIdx.y == 0) {          // one writer per pixel (the bin-block replicas skip it)
       float4 *cp = P.cache + ((long long)b * P.npix + base + lane) * 2;
       cp[0] = make_float4(a, bb, c, iy);
@@ -316,15 +405,19 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
     // prefetch the next 64 pixels while this batch is in the MFMA loop
     if (base + 64 + lane < end) sample_rgb(P, xb, base + 64 + lane, r_, g_, b_);
     lds_wave_sync();
-    const int steps = (min(64, end - base) + 1) >> 1;
+    // K steps of this batch, rounded up to an even count: entries past the batch hold zero weights (written above), so
+    // the padding step adds exact zeros and the loop body needs no branch between its two steps
+    const int steps = (((min(64, end - base) + 1) >> 1) + 1) & ~1;
+    HG_PROBE_T(pb1);
     // Software-pipelined K loop: the operands of step m+1 (VALU: 3..6 kernel vectors) are generated next to the
     // 3*T*T MFMAs of step m.
     // one K step: the MFMAs of `use` while the operands of the following step are generated into `gen` from qn; the
     // float4 two steps ahead is fetched from LDS meanwhile (its latency is covered by a whole step of MFMAs even when
     // the two waves of a SIMD run phase-locked)
-    auto kstep = [&](const Ops<T> &use, Ops<T> &gen, const float4 &qn, float4 &qf, int mf) __attribute__((always_inline)) {
-      qf = stage[wave * 64 + 2 * min(mf, steps - 1) + half];   // {a, b, c, weight}; broadcast per half-wave
-      make_ops(qn, gen);
+    const f32x4 *srow = reinterpret_cast<const f32x4 *>(stage) + wave * kFwdStage + half;
+    auto kstep = [&](const Ops<T> &use, Ops<T> &gen, const f32x4 &qn, f32x4 &qf, int mf) __attribute__((always_inline)) {
+      qf = srow[2 * mf];                                   // {a, b, c, weight}; broadcast per half-wave
+      if constexpr (!(SHARE && HG_FWD_SHARE_ASM)) make_ops(qn, gen);
 #pragma unroll
       for (int ti = 0; ti < T; ++ti)
 #pragma unroll
@@ -333,6 +426,14 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
           acc[1][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(use.A1[ti], use.B1[tj], acc[1][ti][tj], 0, 0, 0);
           if (!green) acc[2][ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(use.A2[ti], use.B2[tj], acc[2][ti][tj], 0, 0, 0);
         }
+      if constexpr (SHARE && HG_FWD_SHARE_ASM) {
+        // the LDS read, the 12 MFMAs as one group, then the operand block of the next step: nothing crosses the fences
+        __builtin_amdgcn_sched_barrier(0);
+        make_ops(qn, gen);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(qf));
+        return;
+      }
 #if HG_FWD_SCHED_GROUPS
       // MFMAs in groups of HG_FWD_MFMA_GROUP with the operand generation of the next step between the groups.  On
       // gfx950 the fp32 MFMA does not hide VALU work (same issue path: tools/ubench/mfma_valu_overlap.hip -- 3 VALU
@@ -346,19 +447,24 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
         __builtin_amdgcn_sched_group_barrier(0x002, HG_FWD_VALU_PER_MFMA * GRP, 0);
       }
 #endif
-      // pin: qf is complete here (after a step's worth of MFMA issue)
-      asm volatile("" : "+v"(qf.x), "+v"(qf.y), "+v"(qf.z), "+v"(qf.w));
+      // pin: qf is complete here (after a step's worth of MFMA issue) -- as ONE 128-bit tuple, so that the packed
+      // operand generation can address its halves in place (op_sel) instead of through copies
+      asm volatile("" : "+v"(qf));
     };
     // two steps per iteration with the operand sets swapping roles: no register copies between steps
     Ops<T> opA, opB;
-    make_ops(stage[wave * 64 + half], opA);
-    float4 qa = stage[wave * 64 + 2 * min(1, steps - 1) + half], qb;
+    make_ops(srow[0], opA);
+    f32x4 qa = srow[2], qb;
     for (int m = 0; m < steps; m += 2) {
       kstep(opA, opB, qa, qb, m + 2);
-      if (m + 1 < steps) kstep(opB, opA, qb, qa, m + 3);
+      kstep(opB, opA, qb, qa, m + 3);
     }
     lds_wave_sync();
+#if HG_HIST_PROBE
+    { HG_PROBE_T(pb2); p_proj += pb1 - pb0; p_loop += pb2 - pb1; }
+#endif
   }
+  HG_PROBE_T(pt2);
 
   // fixed-order sum of the 4 waves' tiles through LDS (deterministic)
   for (int w = 0; w < 4; ++w) {
@@ -402,6 +508,15 @@ __global__ __launch_bounds__(256, 2) void k_hist_fwd(const DevParams P, const fl
   __syncthreads();
   tsum = hg_block_sum_256(tsum, reinterpret_cast<float *>(smem));
   if (threadIdx.x == 0) slab_tot[((long long)b * S + s) * gridDim.y + blockIdx.y] = (double)tsum;
+#if HG_HIST_PROBE
+  if (lane == 0) {
+    HG_PROBE_T(pt3);
+    atomicAdd(&hg_probe[0][0], 1ull); atomicAdd(&hg_probe[0][1], (unsigned long long)(pt3 - pt0));
+    atomicAdd(&hg_probe[0][2], (unsigned long long)(pt1 - pt0)); atomicAdd(&hg_probe[0][3], (unsigned long long)p_proj);
+    atomicAdd(&hg_probe[0][4], (unsigned long long)p_loop); atomicAdd(&hg_probe[0][5], (unsigned long long)(pt3 - pt2));
+    atomicMax(&hg_probe[0][6], (unsigned long long)(pt3 - pt0));
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -488,6 +603,10 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
   const int b = blockIdx.y, s_ = blockIdx.x;
   const float *xb = x + (long long)b * P.sb;
   constexpr bool green = GREEN;
+  HG_PROBE_T(pt0);
+#if HG_HIST_PROBE
+  long long p_state = 0, p_loop = 0, p_epi = 0;
+#endif
 
   {
     const int h = P.h, n = P.P * h * h;
@@ -511,6 +630,7 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
   }
   __syncthreads();
   const float *G0 = G, *G1 = G + BLK * LD, *G2 = G + 2 * BLK * LD;
+  HG_PROBE_T(pt1);
 
   const long long wstart = ((long long)(s_ * 4 + wave) * rounds_per_wave) * 32;
   for (int rd = 0; rd < rounds_per_wave; ++rd) {
@@ -518,6 +638,7 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
     if (n0 >= P.npix) break;
     const int n = (int)n0 + q;
     const bool valid = n < P.npix;
+    HG_PROBE_T(pr0);
     float r_, g_, b_, a, bb, c, iy;
     pixel_state(P, xb, b, n, valid, r_, g_, b_, a, bb, c, iy);
 
@@ -593,6 +714,7 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
       }
     };
     BOps<T> cur;
+    HG_PROBE_T(pr1);
     make_bops(0, cur);
     {                                        // K step 0, peeled: C = 0
       BOps<T> nxt;
@@ -653,6 +775,7 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
       cur = nxt;
     }
 
+    HG_PROBE_T(pr2);
     // epilogue: this lane holds W[v][t][r] for bin beta0(16t+r)+4*half of pixel q.
     // The empty asm makes the eval inputs opaque so the compiler re-evaluates (4 VALU ops each)
     // instead of keeping 2 x 48*T values alive across the MFMA loop (CSE would cost ~190 VGPRs).
@@ -711,7 +834,19 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
     if (valid && half == 1 && P.mode == HG_RESIZE_NONE) {
       for (int cc = 3; cc < P.C; ++cc) gdst[((long long)b * P.C + cc) * P.npix + n] = 0.f;
     }
+#if HG_HIST_PROBE
+    { HG_PROBE_T(pr3); p_state += pr1 - pr0; p_loop += pr2 - pr1; p_epi += pr3 - pr2; }
+#endif
   }
+#if HG_HIST_PROBE
+  if (lane == 0) {
+    HG_PROBE_T(pt3);
+    atomicAdd(&hg_probe[1][0], 1ull); atomicAdd(&hg_probe[1][1], (unsigned long long)(pt3 - pt0));
+    atomicAdd(&hg_probe[1][2], (unsigned long long)(pt1 - pt0)); atomicAdd(&hg_probe[1][3], (unsigned long long)p_state);
+    atomicAdd(&hg_probe[1][4], (unsigned long long)p_loop); atomicAdd(&hg_probe[1][5], (unsigned long long)p_epi);
+    atomicMax(&hg_probe[1][6], (unsigned long long)(pt3 - pt0));
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1921,12 +2056,30 @@ DevParams make_dev(const hg_hist_params *p) {
   return d;
 }
 
+// The shared-reciprocal operand generation of k_hist_fwd forms products of four denominators 1 + t^2, |t| <= (13.9 +
+// max|boundary|) / sigma (log-chroma differences of clamped pixels lie in [-13.82, 13.82]): taken only when that product
+// stays below 1e30 (its reciprocal then is a normal float with room to spare).  HG_FWD_SHARE_RCP=0 switches it off (A/B).
+bool fwd_share_rcp_ok(const DevParams &d) {
+  static const bool enabled = [] { const char *e = getenv("HG_FWD_SHARE_RCP"); return !(e && e[0] == '0'); }();
+  if (!enabled || d.proj != HG_PROJ_RGBUV) return false;
+  const double bmax = fabs(d.lo) > fabs(d.hi) ? fabs(d.lo) : fabs(d.hi);
+  const double tmax = (13.9 + bmax) * d.inv_sigma_x, den = 1.0 + tmax * tmax;
+  return den * den * den * den < 1e30;
+}
+
 template <int T, int METHOD, bool GREEN>
 int launch_fwd_tmg(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, double *slab_tot,
                    hipStream_t st) {
   const dim3 grid(pl.S_fwd, pl.nbd * pl.nbd, d.B), block(256);
-  const size_t lds = 4 * 64 * 16 + (size_t)3 * pl.BLK * pl.BLK * sizeof(float);
+  const size_t lds = 4 * kFwdStage * 16 + (size_t)3 * pl.BLK * pl.BLK * sizeof(float);
   const bool diag = pl.nbd == 1;
+  if constexpr (T == 2 && METHOD == HG_METHOD_INVERSE_QUADRATIC && !GREEN) {
+    if (sym && diag && fwd_share_rcp_ok(d)) {
+      hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, true, GREEN, true>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
+      HG_LAUNCH_CHECK();
+      return HG_OK;
+    }
+  }
   if (sym && diag) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, true, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
   else if (sym) hipLaunchKernelGGL((k_hist_fwd<T, METHOD, true, false, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
   else hipLaunchKernelGGL((k_hist_fwd<T, METHOD, false, false, GREEN>), grid, block, lds, st, d, x, slabs, slab_tot, pl.chunk);
@@ -2004,6 +2157,16 @@ int launch_bwd_planes(const DevParams &d, const Plan &pl, const float *x, const 
 }  // namespace
 
 extern "C" {
+
+#if HG_HIST_PROBE
+// experiment builds only (not declared in include/hg_hist.h): copy the probe counters out and reset them
+int hg_debug_hist_probe(unsigned long long *out16) {
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(hg_probe), sizeof(unsigned long long) * 16);
+  if (e != hipSuccess) return (int)e;
+  unsigned long long z[16] = {0};
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(hg_probe), z, sizeof(z));
+}
+#endif
 
 int hg_version(void) { return HG_VERSION_NUM; }
 
