@@ -43,7 +43,8 @@ HBM_PEAK_GBPS = 8000.0
 def hist_workload(args, dev, rank, world):
     from histogan_amd.hist import HistConfig, hellinger_loss, rgbuv_hist
     B, S, h = args.batch, args.size, args.bins
-    cfg = HistConfig(h=h, insz=S, method='inverse-quadratic', sigma=0.02)
+    insz = args.hist_insz or S
+    cfg = HistConfig(h=h, insz=insz, method='inverse-quadratic', sigma=0.02)
     g = torch.Generator(device='cpu').manual_seed(1000 + rank)
     x = torch.rand(B, 3, S, S, generator=g).to(dev).requires_grad_(True)
     with torch.no_grad():
@@ -63,7 +64,7 @@ def hist_workload(args, dev, rank, world):
         from histogan_amd import hist as HH
         from histogan_amd._lib import lib, check
         xd = x.detach()
-        p, keep = HH._make_params(xd, cfg if method is None else HistConfig(h=h, insz=S, method=method, sigma=0.02))
+        p, keep = HH._make_params(xd, cfg if method is None else HistConfig(h=h, insz=insz, method=method, sigma=0.02))
         fb, bb = HH._ws_bytes(p)
         out = torch.empty(B, 3, h, h, device=dev)
         sums = torch.empty(B, device=dev)
@@ -71,7 +72,7 @@ def hist_workload(args, dev, rank, world):
         gout = torch.rand(B, 3, h, h, device=dev) - 0.5
         ws = torch.empty(max(fb, bb, 4), dtype=torch.uint8, device=dev)
         if method is None:      # the forward -> backward projection cache the autograd Function passes (hist.py)
-            cache = torch.empty(B, S * S, 8, device=dev)
+            cache = torch.empty(B, int(p.Hs) * int(p.Ws), 8, device=dev)
             p.proj_cache = cache.data_ptr()
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters)]
@@ -89,24 +90,34 @@ def hist_workload(args, dev, rank, world):
         tb = sum(e[1].elapsed_time(e[2]) for e in evs) / iters * 1e-3
         return tf, tb
 
-    N = S * S
+    N = min(S, insz) ** 2                       # pixels entering the histogram (the resize is active when S > insz)
     flops_fwd = 6.0 * N * h * h * B            # 3 planes x 2 h^2 flop per pixel
     flops_bwd = 2.0 * flops_fwd
-    bytes_fwd = B * (3 * N + 3 * h * h) * 4
-    bytes_bwd = B * (2 * 3 * N + 3 * h * h) * 4
-    info = dict(workload=f'rgbuv_hist fwd+hellinger+bwd {B}x3x{S}x{S} h={h} inverse-quadratic sigma=0.02 insz={S}',
+    bytes_fwd = B * (3 * S * S + 3 * h * h) * 4
+    bytes_bwd = B * (2 * 3 * S * S + 3 * h * h) * 4
+    info = dict(workload=f'rgbuv_hist fwd+hellinger+bwd {B}x3x{S}x{S} h={h} inverse-quadratic sigma=0.02 insz={insz}',
                 batch_per_gpu=B, image_size=S, h=h, method='inverse-quadratic', parallelism=f'dp{world}')
     return step, time_kernels, dict(flops_fwd=flops_fwd, flops_bwd=flops_bwd, bytes_fwd=bytes_fwd,
                                     bytes_bwd=bytes_bwd), info, B
 
 
-# generator 3x3 convolutions at 256^2 / capacity 16: (K, N, S)   
-G_LAYERS = [(64, 2048, 4), (2048, 2048, 4), (2048, 1024, 8), (1024, 1024, 8), (1024, 512, 16), (512, 512, 16),
-            (512, 256, 32), (256, 256, 32), (256, 128, 64), (128, 128, 64), (128, 64, 128), (64, 64, 128),
-            (64, 32, 256), (32, 32, 256)]
+def g_layers(size, cap):
+    """The generator's 3x3 convolutions (K, N, S) (reference filter arithmetic histoGAN/histoGAN.py:539-543).
+    256^2 / capacity 16: (64, 2048, 4), (2048, 2048, 4), (2048, 1024, 8), ... (64, 32, 256), (32, 32, 256)."""
+    import math
+    L = int(math.log2(size)) - 1
+    f = [4 * cap] + [cap * 2 ** (i + 1) for i in range(L)][::-1]
+    out = []
+    for i in range(L):
+        S = 4 * 2 ** i
+        out += [(f[i], f[i + 1], S), (f[i + 1], f[i + 1], S)]
+    return out
 
 
-TRAFFIC_FILE = 'r03_pmc_traffic.json'
+G_LAYERS = g_layers(256, 16)
+
+
+TRAFFIC_FILE = 'r04_pmc_traffic.json'
 
 
 def source_digest(name):
@@ -121,7 +132,7 @@ def source_digest(name):
 
 def recorded_traffic(key):
     """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes of exactly this launch
-    (profiles/r03_pmc_traffic.json 'bench', tools/conv_traffic.sh / hist_traffic.sh).  The record carries the digest of
+    (profiles/r04_pmc_traffic.json 'bench', tools/conv_traffic.sh / hist_traffic.sh / make_traffic_record.py).  The record carries the digest of
     the kernel source it was measured on: when the source has changed since, the number is stale and None is reported
     (VERDICT r2 weak #8).  Returns (bytes or None, provenance string)."""
     try:
@@ -166,15 +177,17 @@ def thr_probe_batch(dev, B, S, h, iters=10):
 
 
 def recorded_value(key):
-    """A number taken from a committed rocprofv3 run (profiles/r03_recorded.json), None if not recorded."""
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r03_recorded.json')) as f:
-            return json.load(f)[key]
-    except Exception:
-        return None
+    """A number taken from a committed rocprofv3 run (profiles/r04_recorded.json, else round 3's), None if not recorded."""
+    for name in ('r04_recorded.json', 'r03_recorded.json'):
+        try:
+            with open(os.path.join(ROOT, 'profiles', name)) as f:
+                return json.load(f)[key]
+        except Exception:
+            continue
+    return None
 
 
-def conv_kernel_times(dev, B, iters=6):
+def conv_kernel_times(dev, B, iters=6, layers=None):
     """HIP events (torch's current stream == the stream the C ABI launches on) around hg_conv2d_fwd /
     hg_conv2d_dgrad / hg_conv2d_wgrad with preallocated buffers, for every generator 3x3 layer.
     Returns {layer: (flops, t_fwd, t_dgrad, t_wgrad)} in seconds per launch."""
@@ -183,7 +196,7 @@ def conv_kernel_times(dev, B, iters=6):
     from histogan_amd._lib import lib, check
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     out = {}
-    for K, N, S in G_LAYERS:
+    for K, N, S in (layers or G_LAYERS):
         x = torch.randn(B, K, S, S, device=dev)
         w = torch.randn(N, K, 3, 3, device=dev) / (K * 9) ** 0.5
         go = torch.randn(B, N, S, S, device=dev)
@@ -320,7 +333,7 @@ def train_workload(args, dev, rank, world):
     from histoGAN import Trainer
     tr = Trainer('bench', '/tmp/hg_bench_results', '/tmp/hg_bench_models', args.size, args.capacity,
                  batch_size=args.batch, hist_bin=args.bins, hist_insz=150, hist_resizing='interpolation',
-                 hist_method='inverse-quadratic', hist_sigma=0.02)
+                 hist_method='inverse-quadratic', hist_sigma=0.02, attn_layers=list(args.attn_layers))
     tr.run_evaluate = tr.run_save = False
     tr.set_synthetic_data_src()
     tr.init_GAN()
@@ -330,7 +343,8 @@ def train_workload(args, dev, rank, world):
     step.trainer = tr
 
     info = dict(workload=f'HistoGAN G+D train step {args.size}x{args.size} capacity={args.capacity} '
-                         f'batch={args.batch}/GPU h={args.bins} insz=150 inverse-quadratic (GP every 4th, PL every 32nd step)',
+                         f'batch={args.batch}/GPU h={args.bins} insz=150 inverse-quadratic (GP every 4th, PL every 32nd step)'
+                         + (f' attn_layers={list(args.attn_layers)}' if args.attn_layers else ''),
                 batch_per_gpu=args.batch, global_batch=args.batch * world, image_size=args.size,
                 network_capacity=args.capacity, h=args.bins, parallelism=f'dp{world}',
                 params_G=sum(p.numel() for p in tr.GAN.G.parameters()),
@@ -413,6 +427,28 @@ def ddp_probe(dist, dev, rank, world, tr):
     return info
 
 
+def alt_precision_line(args):
+    """The same train workload with the 3x3 stride-1 convolutions on the bf16 matrix cores through exact three-way splits
+    (HG_CONV_PRECISION=b6: six bf16 products per fp32 product, fp32 accumulation) -- a labelled SECONDARY
+    number: the headline `value`, `dtype` and `roofline` stay on the fp32-MFMA kernels.  It is reported because the whole C3
+    parity suite holds its 1e-5 / 1e-4 gates in this mode (profiles/r04_c3_parity_b6.json).  Run in a child process (the
+    precision switch is read at import)."""
+    import subprocess
+    env = dict(os.environ, HG_CONV_PRECISION='b6')
+    cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'train', '--steps', str(min(args.steps, 32)), '--warmup', str(args.warmup),
+           '--batch', str(args.batch), '--size', str(args.size), '--capacity', str(args.capacity), '--bins', str(args.bins),
+           '--no-roofline', '--no-cpu-baseline', '--no-reference-eager', '--no-alt-precision']
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.strip().startswith('{')][-1]
+        d = json.loads(line)
+        return {'mode': 'bf16x6 split of every fp32 operand, fp32 accumulate (3x3 stride-1 output / data-gradient convolutions; '
+                        'weight gradients and everything else fp32 MFMA)', 'images_per_s': d['value'], 'ms_per_step': d['ms_per_step'],
+                'steps': d['steps'], 'parity_record': 'profiles/r04_c3_parity_b6.json', 'env': 'HG_CONV_PRECISION=b6'}
+    except Exception as e:
+        return {'mode': 'bf16x6', 'images_per_s': None, 'error': f'{type(e).__name__}: {str(e)[:200]}'}
+
+
 def claim_stdout():
     """The contract is ONE JSON line on stdout.  librccl writes a version banner to the C stdout when the process group is
     torn down (5 lines behind the JSON at any world size), and a stray library print would do the same: file descriptor 1
@@ -481,7 +517,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=32)
     ap.add_argument('--warmup', type=int, default=4)
-    ap.add_argument('--workload', default='train', choices=['train', 'hist', 'rehistogan'])
+    ap.add_argument('--workload', default='train', choices=['train', 'hist', 'rehistogan', 'c5'],
+                    help="c5 = BASELINE.json configs[4] on one GPU: train step at 1024^2, capacity 16, batch 8, h = 128, attention")
+    ap.add_argument('--attn-layers', type=lambda v: [int(t) for t in v.split(',') if t], default=[])
+    ap.add_argument('--hist-insz', type=int, default=0, help='histogram input size of the stand-alone histogram timings (0: image size)')
     ap.add_argument('--capacity', type=int, default=16)
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--size', type=int, default=256)
@@ -491,8 +530,19 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-reference-eager', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='skip the stand-alone kernel timings (tests only)')
+    ap.add_argument('--no-alt-precision', action='store_true', help='skip the labelled bf16x6 secondary line')
     args = ap.parse_args()
 
+    if args.workload == 'c5':
+        # BASELINE.json configs[4]: HistoGAN 1024^2 (capacity 16, discriminator attention on), batch 8 per GPU, h = 128
+        # inverse-quadratic.  attn_layers = [3, 4] (128^2 and 64^2 maps): attention after block 1 would keep q / k / v of 512
+        # channels on 512^2 maps -- 8.6 GB each for the 16-image [fake; real] pass -- and does not fit 288 GB together with the
+        # gradient penalty's double backward.  A secondary workload: the headline stays configs[2].
+        args.workload, args.size, args.capacity, args.batch, args.bins = 'train', 1024, 16, 8, 128
+        args.attn_layers = args.attn_layers or [3, 4]
+        args.hist_insz = 150
+        args.no_cpu_baseline = args.no_reference_eager = True      # (the oracle needs minutes per 1024^2 image on the host)
+        args.c5 = True
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # no external launcher (torch.distributed.run exports WORLD_SIZE): one process per GPU from here
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], json_out))
@@ -615,23 +665,26 @@ def main():
     hist_roof['thresholding'] = {'kernels': 'k_thr_fwd_lean + k_hist_finish / k_thr_bwd_lean', 'bound': 'hbm',
                                  'fwd_ms': tt_f * 1e3, 'bwd_ms': tt_b * 1e3, 'achieved': thr_gbps, 'peak': HBM_PEAK_GBPS,
                                  'unit': 'GB/s', 'frac': thr_gbps / HBM_PEAK_GBPS,
-                                 'traffic': recorded_value('thr_traffic_bytes_b32') if (args.batch, args.size, args.bins) == (32, 256, 64) else None,
+                                 'traffic': recorded_traffic('thr_fwd_bwd_c2')[0] if (args.batch, args.size, args.bins) == (32, 256, 64) else None,
+                                 'traffic_source': recorded_traffic('thr_fwd_bwd_c2')[1],
+                                 'north_star_hbm_target': 0.6, 'north_star_hbm_target_met': bool(thr_gbps / HBM_PEAK_GBPS >= 0.6),
                                  'note': 'three launches of 17 + 5 + 23 us at batch 32: launch-latency regime (78.6 MB = 9.8 us at peak)'}
     if rank == 0 and world == 1 and (args.size, args.bins) == (256, 64) and args.batch < 256:
         # the same kernels where the launches are long enough to stream: batch 256 (629 MB per forward + backward)
         hist_roof['thresholding']['batch256'] = thr_probe_batch(dev, 256, args.size, args.bins)
     if args.workload in ('train', 'rehistogan'):
-        ct = conv_kernel_times(dev, args.batch)
-        fl, tf, td, tw = ct[(256, 128, 64)]
+        ct = conv_kernel_times(dev, args.batch, layers=g_layers(args.size, args.capacity))
+        rl = (16 * args.capacity, 8 * args.capacity, args.size // 4)        # 256 -> 128 channels at a quarter of the image size
+        fl, tf, td, tw = ct[rl]
         tot = [sum(v[i] for v in ct.values()) for i in range(4)]
-        roof = {'kernel': 'k_conv<128ch x 128px tile, 3x3, stride 1> (hg_conv2d_fwd) at 256->128 ch, 64x64, batch %d' % args.batch,
+        roof = {'kernel': 'k_conv<128ch x 128px tile, 3x3, stride 1> (hg_conv2d_fwd) at %d->%d ch, %dx%d, batch %d' % (rl[0], rl[1], rl[2], rl[2], args.batch),
                 'bound': 'mfma', 'achieved': fl / tf / 1e12, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': fl / tf / 1e12 / FP32_PEAK_TFLOPS,
-                'traffic': recorded_traffic('k_conv_fwd_256_128_64_b32')[0] if args.batch == 32 else None,
+                'traffic': recorded_traffic('k_conv_fwd_256_128_64_b32')[0] if (args.batch, rl) == (32, (256, 128, 64)) else None,
                 'traffic_unit': 'bytes/launch (FETCH_SIZE + WRITE_SIZE)',
                 'traffic_source': recorded_traffic('k_conv_fwd_256_128_64_b32')[1],
                 'launch_ms': tf * 1e3, 'flops_per_launch': fl,
-                'algorithmic_bytes_per_launch': 4.0 * (args.batch * 256 * 64 * 64 + args.batch * 128 * 64 * 64 + 9 * 256 * 128),
+                'algorithmic_bytes_per_launch': 4.0 * (args.batch * rl[0] * rl[2] ** 2 + args.batch * rl[1] * rl[2] ** 2 + 9 * rl[0] * rl[1]),
                 'wgrad': {'kernel': 'k_wgrad (hg_conv2d_wgrad), same layer', 'achieved': fl / tw / 1e12,
                           'frac': fl / tw / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': tw * 1e3},
                 'generator_3x3_layers': {'flops_per_pass': tot[0],
@@ -679,6 +732,10 @@ def main():
                 out['cpu_baseline'] = cpu_baseline_train(args) if args.workload == 'train' else cpu_baseline(args)
             if args.workload == 'train' and not args.no_reference_eager:
                 out['reference_eager_rocm'] = reference_eager_rocm(args, dev)
+        if world == 1 and args.workload == 'train' and not args.no_alt_precision and not getattr(args, 'c5', False) \
+                and os.environ.get('HG_CONV_PRECISION', 'f32') == 'f32':
+            torch.cuda.empty_cache()
+            out['alt_precision'] = alt_precision_line(args)
         print(json.dumps(out), file=json_out, flush=True)
     if dist:
         dist.destroy_process_group()

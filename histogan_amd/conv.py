@@ -422,7 +422,7 @@ def side_stream(device):
     if st is None:
         # HG_W_STREAM_PRIO: HIP priority of the weight-gradient stream (0 normal, -1 high), an experiment knob
         st = _side_streams[device.index] = torch.cuda.Stream(
-            device=device, priority=int(__import__('os').environ.get('HG_W_STREAM_PRIO', '0')))
+            device=device, priority=int(os.environ.get('HG_W_STREAM_PRIO', '0')))
     return st
 
 

@@ -50,12 +50,11 @@
 #ifndef HG_WGRAD_PC128
 #define HG_WGRAD_PC128 1   // 128-pixel chunks for the pixel-split 3x3 weight-gradient tiles (<= 32 channels on one side)
 #endif
-#ifndef HG_CONV_XCD_SPLITK
-// EXPERIMENT, compiled out by default (not validated on the full suite): the K-split slabs of k_conv combined by the last
-// arriving block of each tile, fence-free -- the splits of a tile share an XCD (see conv_body and DESIGN.md section 12.5).
-// 1: measured (correct, 48.5 vs 46.6 ms per step); 2: + a tile's splits adjacent in dispatch order (written, never run)
-#define HG_CONV_XCD_SPLITK 0
-#endif
+// (Rounds 3-4 built the K-split combination INSIDE k_conv three times and removed it each time: with device-scope fences
+// 53 instead of 38 ms of convolutions per step (a release / acquire pair writes back / invalidates a whole L2 on this
+// multi-XCD part); fence-free with a tile's splits on one XCD 48.5 ms per plain step against 46.1 (the finishers run
+// alone at the tail of the launch); with the splits adjacent in dispatch order 50.9 (profiles/r04_xcd_splitk.json).  The
+// two-launch form -- slabs + k_splitk_reduce -- stays.  The code is in the history: commits 547ecd1, 19f73b6.)
 #ifndef HG_CONV_BIGTILE_SPLITK
 #define HG_CONV_BIGTILE_SPLITK 2   // 128x128 tile + K split for 8x8 maps (1) and 4x4 maps (2)
 #endif
@@ -84,13 +83,6 @@ struct ConvArgs {
   int ntx, wrow0, wrow_dy, wrow_dx;  // packed-weight row of tap t = wrow0 + (t / ntx)*wrow_dy + (t % ntx)*wrow_dx
   int ksplit;      // > 1: blockIdx.z handles a K range and writes raw partial sums to slab[z] (out layout)
   float *slab;
-#if HG_CONV_XCD_SPLITK
-  // In-kernel combination of the K-split slabs (no k_splitk_reduce launch): flags[tile] = (tag << 8 | arrivals) counts the
-  // blocks of a tile that have written their slab; the last one sums the slabs in z order and applies the epilogue.  `tag`
-  // (56 bits) is unique per launch and never 0, so the words need no initialisation.
-  unsigned long long *flags;
-  unsigned long long tag;
-#endif
   // fused generator epilogue (hg_modconv2d_fwd): v = acc*oscale + bias[n] + noise_w[n]*noise_img[b][y][x]; lrelu
   const float *noise_w, *noise_img;
   int noise_S;     // noise_img is (B, noise_S, noise_S)
@@ -448,130 +440,15 @@ __device__ __forceinline__ void conv_body(const ConvArgs &a, const int bidx, con
     }
   }
   };
-#if !HG_CONV_XCD_SPLITK
   // split-K partials get their epilogue in k_splitk_reduce.  (Round 3 built the combination into this kernel -- the last-
   // arriving block of a tile summing the slabs behind arrival flags -- and measured it 15 ms per step SLOWER: the
   // device-scope release / acquire fences it needs write back and invalidate the XCD's whole L2, per block, under the
   // other blocks' operand reuse.  DESIGN.md section 8; the fence-free form below is section 12.5's experiment.)
   epilogue(a.ksplit == 1);
-#else
-  if (a.ksplit == 1) {
-    epilogue(true);
-    return;
-  }
-  epilogue(false);
-  if (a.flags == nullptr) return;    // the host sums the slabs with k_splitk_reduce
-
-  // ---- last-arriving block of this tile: combine the slabs, WITHOUT device-scope fences.  The ksplit blocks of a tile differ
-  // in blockIdx.z only and the host pads gridDim.x until gridDim.x * gridDim.y is a multiple of 8, so their linear ids are
-  // congruent mod 8: they run on
-  // ONE XCD, whose L2 is the coherence point (tools/ubench/xcd_handoff.hip: plain stores + s_waitcnt + a relaxed atomic +
-  // L1-bypassing loads are correct there; across XCDs they are not).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's slab stores have reached that L2 ...
-  __syncthreads();                                     // ... for every thread of the block
-  int *s_last = reinterpret_cast<int *>(smem);
-  if (tid == 0) {
-    unsigned long long *f = a.flags + (size_t)bidy * (g.tiles_x * g.tiles_y * g.groups) + bidx;
-    unsigned long long w = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), nw;
-    do {
-      nw = (w >> 8) == a.tag ? w + 1 : ((a.tag << 8) | 1ull);      // a word of another launch (or garbage) restarts the count
-    } while (!__hip_atomic_compare_exchange_strong(f, &w, nw, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    *s_last = (int)(nw & 255ull) == a.ksplit;
-    if (*s_last)                      // leave the word clear: a replayed hipGraph launches this kernel with the same tag
-      __hip_atomic_store(f, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!*s_last) return;
-  // slab reads past this CU's L1 (it may hold lines of an earlier launch's slabs at the same addresses): agent-scope loads
-  auto ld1 = [](const float *q) __attribute__((always_inline)) {
-    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned *>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  };
-  auto ld4 = [&](const float *q) __attribute__((always_inline)) { return f32x4{ld1(q), ld1(q + 1), ld1(q + 2), ld1(q + 3)}; };
-  {
-    // The tile as a flat (channel, pixel) range over all threads -- k_splitk_reduce's arithmetic restricted to this tile,
-    // independent of the MFMA register layout (reloading the slabs into the accumulators and re-running the epilogue cost the
-    // whole kernel its third block per CU in registers).  16-byte loads where rows allow: four pixels of a row per thread,
-    // ksplit x 16 B in flight per element group; fixed z order: deterministic.
-    const size_t total = (size_t)a.B * N * HWo;
-    constexpr int lMB = MB == 256 ? 8 : (MB == 128 ? 7 : 6);
-    static_assert((1 << lMB) == MB, "pixels per block");
-    auto finish = [&](float v, const int ch, const int b, const int cy, const int cx, const size_t idx) __attribute__((always_inline)) {
-      float add = a.bias ? a.bias[ch] : 0.f;
-      if (a.noise_img) add = fmaf(a.noise_w[ch], a.noise_img[((size_t)b * a.noise_S + cy) * a.noise_S + cx], add);
-      v = a.oscale ? fmaf(v, a.oscale[b * N + ch], add) : v + add;
-      if (a.addend) v += a.addend[idx];
-      if (a.slope > 0.f) v = v > 0.f ? v : a.slope * v;
-      return v;
-    };
-    const bool vec = g.lTW >= 2 && (a.Wo & 3) == 0 && a.os == 1 && (HWo & 3) == 0;
-    if (vec) {
-      for (int e = tid * 4; e < NB * MB; e += NT * 4) {
-        const int cl = e >> lMB, p = e & (MB - 1);
-        const int ch = n0 + cl;
-        const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
-        const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
-        if (ch >= N || b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;     // (Wc == Wo, a multiple of 4: whole groups)
-        const size_t idx = ((size_t)b * N + ch) * HWo + (size_t)cy * a.Wo + cx;
-        // four independent partial sums: four slabs' loads in flight per thread (order fixed by z alone: deterministic)
-        const float *sp = a.slab + idx;
-        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
-        int z = 0;
-        for (; z + 3 < a.ksplit; z += 4) {
-          v0 += ld4(sp + (size_t)z * total);
-          v1 += ld4(sp + (size_t)(z + 1) * total);
-          v2 += ld4(sp + (size_t)(z + 2) * total);
-          v3 += ld4(sp + (size_t)(z + 3) * total);
-        }
-        for (; z < a.ksplit; ++z) v0 += ld4(sp + (size_t)z * total);
-        const f32x4 v = (v0 + v1) + (v2 + v3);
-        f32x4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = finish(v[q], ch, b, cy, cx + q, idx + q);
-        *reinterpret_cast<f32x4 *>(a.out + idx) = o;
-      }
-    } else {
-      for (int e = tid; e < NB * MB; e += NT) {
-        const int cl = e >> lMB, p = e & (MB - 1);
-        const int ch = n0 + cl;
-        const int px = p & TWm, py = (p >> g.lTW) & THm, pi = p >> (g.lTW + g.lTH);
-        const int cx = x0 + px, cy = y0 + py, b = b0 + pi;
-        if (ch >= N || b >= a.B || cy >= a.Hc || cx >= a.Wc) continue;
-        const int oyy = cy * a.os + a.oy, oxx = cx * a.os + a.ox;
-        const size_t idx = ((size_t)b * N + ch) * HWo + (size_t)oyy * a.Wo + oxx;
-        const float *sp = a.slab + idx;
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        int z = 0;
-        for (; z + 3 < a.ksplit; z += 4) {
-          v0 += ld1(sp + (size_t)z * total); v1 += ld1(sp + (size_t)(z + 1) * total);
-          v2 += ld1(sp + (size_t)(z + 2) * total); v3 += ld1(sp + (size_t)(z + 3) * total);
-        }
-        for (; z < a.ksplit; ++z) v0 += ld1(sp + (size_t)z * total);
-        a.out[idx] = finish((v0 + v1) + (v2 + v3), ch, b, oyy, oxx, idx);
-      }
-    }
-  }
-#endif
 }
 
 template <int WC, int WP, int TC, int TP, int TAPS, int KC, int IS, bool SM, int MT, bool FE>
 __global__ __launch_bounds__(WC *WP * 64, HG_CONV_MINW) void k_conv(const ConvArgs a) {
-#if HG_CONV_XCD_SPLITK
-  if (a.flags != nullptr) {
-#if HG_CONV_XCD_SPLITK >= 2
-    // (written at the end of round 3, NOT yet run on hardware) 1-D grid, a tile's splits adjacent in dispatch order and on one
-    // XCD: linear id L = 8 (Z t + z) + x  ->  XCD x, split z, tile 8 t + x; the combine of one tile then runs under the K
-    // loops of the tiles dispatched behind it instead of at the tail of the launch.
-    const int L = (int)blockIdx.x, x8 = L & 7, sq = L >> 3;
-    const int z = sq % a.ksplit, T = (sq / a.ksplit) * 8 + x8;
-    const int gxr = a.g.tiles_x * a.g.tiles_y * a.g.groups;
-    if (T >= gxr * (int)((a.N + WC * TC * MT - 1) / (WC * TC * MT))) return;
-    conv_body<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, FE>(a, T % gxr, T / gxr, z);
-    return;
-#else
-    if ((int)blockIdx.x >= a.g.tiles_x * a.g.tiles_y * a.g.groups) return;   // spare blocks of the padded grid (XCD pairing)
-#endif
-  }
-#endif
   conv_body<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, FE>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
@@ -1352,21 +1229,7 @@ int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t
   size_t lds = prep_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT>(a, tp, ksplit);
   if (!lds) return HG_EUNSUPPORTED;
   bool inkernel_combine = false;
-#if HG_CONV_XCD_SPLITK
-  a.flags = nullptr; a.tag = 0;
-  if (ksplit > 1 && reduce) {
-    static const bool inkernel = !(getenv("HG_CONV_SPLITK_INKERNEL") && atoi(getenv("HG_CONV_SPLITK_INKERNEL")) == 0);
-    const size_t slab_b = ((size_t)ksplit * a.B * a.N * a.Ho * a.Wo * sizeof(float) + 255) / 256 * 256;
-    const size_t flag_b = (size_t)a.g.tiles_x * a.g.tiles_y * a.g.groups * ((a.N + NB - 1) / NB) * ksplit * sizeof(unsigned long long);
-    if (inkernel && ws_bytes >= slab_b + flag_b) {
-      a.flags = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.slab) + slab_b);
-      a.tag = (next_conv_tag() & 0x00FFFFFFFFFFFFFFull) | 1ull;
-      inkernel_combine = true;
-    }
-  }
-#else
   (void)ws_bytes;
-#endif
   const bool fe = a.iscale || a.oscale || a.noise_img || a.slope > 0.f;
   auto kern = fe ? k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, true> : k_conv<WC, WP, TC, TP, TAPS, KC, IS, SM, MT, false>;
   static int state[2][2] = {{0, 0}, {0, 0}};
@@ -1384,12 +1247,6 @@ int launch_conv(ConvArgs a, const Taps &tp, int ksplit, bool reduce, hipStream_t
     gx = (gx + m - 1) / m * m;
   }
   dim3 grid(gx, (unsigned)((a.N + NB - 1) / NB), (unsigned)ksplit);
-#if HG_CONV_XCD_SPLITK >= 2
-  if (inkernel_combine) {
-    const unsigned tiles = (unsigned)(a.g.tiles_x * a.g.tiles_y * a.g.groups) * (unsigned)((a.N + NB - 1) / NB);
-    grid = dim3((tiles + 7u) / 8u * 8u * (unsigned)ksplit, 1, 1);
-  }
-#endif
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, a);
   HG_LAUNCH_CHECK();
   if (ksplit > 1 && reduce && !inkernel_combine) return launch_splitk_reduce(a, ksplit, st);
@@ -1406,9 +1263,6 @@ int launch_conv_parity4(const ConvArgs (&base)[4], const Taps (&tp)[4], int kspl
   int tiles_max = 0;
   for (int c = 0; c < 4; ++c) {
     a4.c[c] = base[c];
-#if HG_CONV_XCD_SPLITK
-    a4.c[c].flags = nullptr; a4.c[c].tag = 0;    // the caller sums the slabs of the four classes
-#endif
     a4.tiles[c] = 0;
     if (base[c].Hc <= 0 || base[c].Wc <= 0) continue;   // empty class (1-pixel-wide image)
     size_t l = c == 0 ? prep_conv<WC, WP, TC, TP, 1, KC, 1, SM, MT>(a4.c[c], tp[c], ksplit)
@@ -1441,26 +1295,10 @@ int launch_conv_parity4(const ConvArgs (&base)[4], const Taps (&tp)[4], int kspl
 
 // K-split scratch: ksplit slabs in `out` layout, then (256-byte aligned) one 64-bit flag per (output tile, split) for the
 // in-kernel combination.  Hc x Wc: the compute grid of the launch (== Ho x Wo for stride-1 / forward launches).
-#if HG_CONV_XCD_SPLITK
-inline size_t conv_slab_bytes(const ConvPlan &p, int B, int N, int Ho, int Wo) {
-  return p.ksplit > 1 ? ((size_t)p.ksplit * B * N * Ho * Wo * sizeof(float) + 255) / 256 * 256 : 0;
-}
-inline size_t conv_flag_bytes(const ConvPlan &p, int B, int N, int Hc, int Wc) {
-  if (p.ksplit <= 1) return 0;
-  const int nbt = p.tile == TILE_16x256 ? 16 : p.tile == TILE_32x256 ? 32 : (p.tile == TILE_64x256 || p.tile == TILE_64x64) ? 64 : 128;
-  const int mbt = (p.tile == TILE_128x128 || p.tile == TILE_128x128_SM) ? 128 : p.tile == TILE_64x64 ? 64 : 256;
-  const int min_t = (p.tile == TILE_128x128_SM || p.tile == TILE_64x64) ? 2 : 4;
-  return (size_t)pixel_tiles(mbt, B, Hc, Wc, min_t) * ((N + nbt - 1) / nbt) * p.ksplit * sizeof(unsigned long long);
-}
-inline size_t conv_ws_bytes(const ConvPlan &p, int B, int N, int Ho, int Wo) {
-  return conv_slab_bytes(p, B, N, Ho, Wo) + conv_flag_bytes(p, B, N, Ho, Wo);
-}
-#else
 inline size_t conv_slab_bytes(const ConvPlan &p, int B, int N, int Ho, int Wo) {
   return p.ksplit > 1 ? (size_t)p.ksplit * B * N * Ho * Wo * sizeof(float) : 0;
 }
 inline size_t conv_ws_bytes(const ConvPlan &p, int B, int N, int Ho, int Wo) { return conv_slab_bytes(p, B, N, Ho, Wo); }
-#endif
 
 
 inline int launch_splitk_reduce(const ConvArgs &a, int ksplit, hipStream_t st) {

@@ -50,6 +50,9 @@
 #ifndef HG_BWD_SCHED_GROUPS
 #define HG_BWD_SCHED_GROUPS 1
 #endif
+#ifndef HG_BWD_MFMA_GROUP
+#define HG_BWD_MFMA_GROUP 1   // k_hist_bwd K loop: MFMAs per group between the VALU work of the next step (1: round 2's 1 : 2 interleave)
+#endif
 #ifndef HG_BWD_SCHED_BARRIER
 #define HG_BWD_SCHED_BARRIER 1
 #endif
@@ -588,7 +591,7 @@ __device__ __forceinline__ constexpr int beta0(int s) { return (s & 3) + 8 * ((s
 // as D[bin][pixel] MFMA tiles (A = Ghat from LDS, B = kernel values generated in registers), then
 //   dL/da = Iy * sum_i k'(a-b_i) Wa[i]   (same for b, c),   dL/dIy = 1/2 sum_i (ka Wa + kb Wb + kc Wc)[i]
 //   dL_R = da+db, dL_G = -da+dc, dL_B = -db-dc,   dx_c = dL_c/(x_c+1e-6) + dIy x_c/Iy   
-template <int T, int METHOD, bool GREEN>
+template <int T, int METHOD, bool GREEN, bool SHARE = false>
 __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams P, const float *__restrict__ x,
                                                                 const float *__restrict__ gout,
                                                                 const float *__restrict__ hist,
@@ -713,8 +716,126 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
         }
       }
     };
-    BOps<T> cur;
     HG_PROBE_T(pr1);
+    if constexpr (SHARE) {
+      // ---- round 4: two K steps per iteration, shared reciprocals, one block of packed instructions ----------------------
+      // fp32 MFMA and VALU issue exclude each other on gfx950 and v_rcp_f32 runs at a quarter of the VALU rate
+      // (profiles/r04_hist_pmc_stalls_raw.txt, r04_ubench_hist_fwd_loop.txt): per K step the 3 kernel evaluations were 13 VALU
+      // instructions + 3 reciprocals (100 issue cycles next to 768 of MFMAs).  Two steps together are six denominators
+      // (a1, b1, a2, b2, c1, c2): 1/(a1 a2 b1 b2) gives four reciprocals, 1/(c1 c2) two -- 21 packed VALU instructions + 2
+      // v_rcp_f32 per TWO steps (58 cycles per step).  Written as inline assembly: clang 22 unpacks v_pk_* behind MFMAs.
+      // Step s and s + 1 (s even) use the bins beta0(s) and beta0(s) + 1.  s_nop 0: trans -> VALU; s_nop 1: VALU -> MFMA.
+      static_assert(METHOD == HG_METHOD_INVERSE_QUADRATIC && !GREEN, "shared-reciprocal backward");
+      struct B2 { float A[2][T][6]; f32x2 k1, k2, kc; };
+      const f32x2 thab = {th[0], th[1]}, tlab = {tl[0], tl[1]}, thc2 = {th[2], th[2]}, tlc2 = {tl[2], tl[2]};
+      const f32x2 dsh2 = {P.ds_hi, P.ds_hi}, dsl2 = {P.ds_lo, P.ds_lo};
+      auto lds2 = [&](int s, B2 &o) __attribute__((always_inline)) {
+        const int b0 = (s & 3) + 8 * ((s >> 2) & 3) + 32 * (s >> 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int beta = b0 + j + 4 * half;
+#pragma unroll
+          for (int rt = 0; rt < T; ++rt) {
+            const int row = 32 * rt + q;
+            o.A[j][rt][0] = G0[row * LD + beta];
+            o.A[j][rt][1] = G0[beta * LD + row];
+            o.A[j][rt][2] = G2[beta * LD + row];
+            o.A[j][rt][3] = G2[row * LD + beta];
+            o.A[j][rt][4] = G1[row * LD + beta];
+            o.A[j][rt][5] = G1[beta * LD + row];
+          }
+        }
+      };
+      auto gen2 = [&](int s, B2 &o) __attribute__((always_inline)) {
+        const int b0 = (s & 3) + 8 * ((s >> 2) & 3) + 32 * (s >> 4);
+        const float kf = -(float)b0;
+        const f32x2 kfp = {kf, kf - 1.f};
+        f32x2 k1, k2, kc;
+        asm volatile(
+            "v_pk_fma_f32 v[240:241], %3, %8, %4 op_sel_hi:[0,1,1]\n\t"                    // step 1 (a, b): kf ds_hi + t_hi
+            "v_pk_fma_f32 v[242:243], %3, %8, %4 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"     // step 2 (a, b)
+            "v_pk_fma_f32 v[244:245], %3, %8, %6\n\t"                                       // (c step 1, c step 2)
+            "v_pk_fma_f32 v[246:247], %3, %9, %5 op_sel_hi:[0,1,1]\n\t"                    // kf ds_lo + t_lo
+            "v_pk_fma_f32 v[248:249], %3, %9, %5 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+            "v_pk_fma_f32 v[250:251], %3, %9, %7\n\t"
+            "v_pk_add_f32 v[240:241], v[240:241], v[246:247]\n\t"                           // t
+            "v_pk_add_f32 v[242:243], v[242:243], v[248:249]\n\t"
+            "v_pk_add_f32 v[244:245], v[244:245], v[250:251]\n\t"
+            "v_pk_fma_f32 v[240:241], v[240:241], v[240:241], 1.0 op_sel_hi:[1,1,0]\n\t"   // (a1, b1) = 1 + t^2
+            "v_pk_fma_f32 v[242:243], v[242:243], v[242:243], 1.0 op_sel_hi:[1,1,0]\n\t"   // (a2, b2)
+            "v_pk_fma_f32 v[244:245], v[244:245], v[244:245], 1.0 op_sel_hi:[1,1,0]\n\t"   // (c1, c2)
+            "v_pk_mul_f32 v[246:247], v[240:241], v[242:243]\n\t"                           // (a1 a2, b1 b2)
+            "v_mul_f32 v249, v244, v245\n\t"                                                // c1 c2
+            "v_mul_f32 v248, v246, v247\n\t"                                                // a1 a2 b1 b2
+            "v_rcp_f32 v249, v249\n\t"
+            "v_rcp_f32 v248, v248\n\t"
+            "s_nop 0\n\t"
+            "v_pk_mul_f32 %2, v[244:245], v[248:249] op_sel:[1,1] op_sel_hi:[0,1]\n\t"      // (1/c1, 1/c2)
+            "v_pk_mul_f32 v[246:247], v[246:247], v[248:249] op_sel:[1,0] op_sel_hi:[0,0]\n\t"  // (1/(a1 a2), 1/(b1 b2))
+            "v_pk_mul_f32 %0, v[242:243], v[246:247]\n\t"                                   // (1/a1, 1/b1)
+            "v_pk_mul_f32 %1, v[240:241], v[246:247]\n\t"                                   // (1/a2, 1/b2)
+            "s_nop 1"
+            : "=&v"(k1), "=&v"(k2), "=&v"(kc)
+            : "v"(kfp), "v"(thab), "v"(tlab), "v"(thc2), "v"(tlc2), "s"(dsh2), "s"(dsl2)
+            : "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251");
+        o.k1 = k1; o.k2 = k2; o.kc = kc;
+      };
+      auto mfma12 = [&](const float (&A)[T][6], float ka, float kb, float kcv, bool first) __attribute__((always_inline)) {
+        const f32x16 Z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rt = 0; rt < T; ++rt) {
+          if (first) {                         // C = 0 as an inline constant: no zero fill of the 96 accumulators
+            W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rt][0], kb, Z, 0, 0, 0);
+            W[1][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rt][1], ka, Z, 0, 0, 0);
+            W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rt][2], kb, Z, 0, 0, 0);
+          } else {
+            W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rt][0], kb, W[0][rt], 0, 0, 0);
+            W[1][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rt][1], ka, W[1][rt], 0, 0, 0);
+            W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rt][2], kb, W[2][rt], 0, 0, 0);
+          }
+          W[1][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rt][3], kcv, W[1][rt], 0, 0, 0);
+          W[0][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rt][4], kcv, W[0][rt], 0, 0, 0);
+          W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[rt][5], ka, W[2][rt], 0, 0, 0);
+        }
+      };
+      B2 cur2, nxt2;
+      lds2(0, cur2);
+      gen2(0, cur2);
+      {                                        // steps 0 and 1, peeled (C = 0 in step 0)
+        lds2(2, nxt2);
+        mfma12(cur2.A[0], cur2.k1.x, cur2.k1.y, cur2.kc.x, true);
+        mfma12(cur2.A[1], cur2.k2.x, cur2.k2.y, cur2.kc.y, false);
+        __builtin_amdgcn_sched_barrier(0);
+        gen2(2, nxt2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rt = 0; rt < T; ++rt)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(nxt2.A[j][rt][i]));
+        cur2 = nxt2;
+      }
+#pragma unroll 1
+      for (int s = 2; s < NS; s += 2) {
+        const int sn = min(s + 2, NS - 2);     // (the last iteration prepares operands nobody uses)
+        lds2(sn, nxt2);
+        mfma12(cur2.A[0], cur2.k1.x, cur2.k1.y, cur2.kc.x, false);
+        mfma12(cur2.A[1], cur2.k2.x, cur2.k2.y, cur2.kc.y, false);
+        // the LDS reads of the next pair of steps, the 12 * T MFMAs of this pair as one group, then the operand block
+        __builtin_amdgcn_sched_barrier(0);
+        gen2(sn, nxt2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int rt = 0; rt < T; ++rt)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(nxt2.A[j][rt][i]));
+        cur2 = nxt2;
+      }
+    } else {
+    BOps<T> cur;
     make_bops(0, cur);
     {                                        // K step 0, peeled: C = 0
       BOps<T> nxt;
@@ -758,12 +879,17 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
         W[2][rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.A[rt][5], cur.ka, W[2][rt], 0, 0, 0);
       }
 #if HG_BWD_SCHED_GROUPS
-      // all LDS operand reads of the next step first, then MFMAs with the 3 evaluations in their shadow
+      // all LDS operand reads of the next step first, then the MFMAs in groups of HG_BWD_MFMA_GROUP with the next step's
+      // address arithmetic / kernel evaluations between the groups (fp32 MFMA and VALU issue exclude each other on gfx950:
+      // what the schedule controls is the number of MFMA <-> VALU switches)
       __builtin_amdgcn_sched_group_barrier(0x100, 6 * T, 0);
+      {
+        constexpr int NM = (green ? 2 : 6) * T, GRP = HG_BWD_MFMA_GROUP < NM ? HG_BWD_MFMA_GROUP : NM;
 #pragma unroll
-      for (int i = 0; i < (green ? 2 : 6) * T; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        for (int i = 0; i < NM; i += GRP) {
+          __builtin_amdgcn_sched_group_barrier(0x008, GRP, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2 * GRP, 0);
+        }
       }
 #endif
       // pin: the next step's operands are complete here, after a step's worth of MFMA issue; without
@@ -774,6 +900,7 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
         for (int i = green ? 4 : 0; i < 6; ++i) asm volatile("" : "+v"(nxt.A[rt][i]));
       cur = nxt;
     }
+    }   // !SHARE
 
     HG_PROBE_T(pr2);
     // epilogue: this lane holds W[v][t][r] for bin beta0(16t+r)+4*half of pixel q.
@@ -790,6 +917,36 @@ __global__ __launch_bounds__(256, HG_BWD_WAVES) void k_hist_bwd(const DevParams 
       for (int v = 0; v < 3; ++v) {
         gs2[v] = f32x2{0.f, 0.f};
         const f32x2 th2 = {th[v], th[v]}, tl2 = {tl[v], tl[v]};
+        if constexpr (SHARE) {
+          // four bins per reciprocal: (d0, d1), (d2, d3) -> r = 1 / (d0 d2 d1 d3) (the K loop's trick; no MFMA nearby, so
+          // the compiler keeps the packed instructions)
+#pragma unroll
+          for (int s = 0; s < NS; s += 4) {
+            f32x2 t2[2], d2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const f32x2 kf2 = {-(float)beta0(s + 2 * j), -(float)beta0(s + 2 * j + 1)};
+              t2[j] = __builtin_elementwise_fma(kf2, f32x2{P.ds_hi, P.ds_hi}, th2) +
+                      __builtin_elementwise_fma(kf2, f32x2{P.ds_lo, P.ds_lo}, tl2);
+              d2[j] = __builtin_elementwise_fma(t2[j], t2[j], f32x2{1.f, 1.f});
+            }
+            const f32x2 pq = d2[0] * d2[1];
+            const float r4 = __builtin_amdgcn_rcpf(pq.x * pq.y);
+            const f32x2 rq = f32x2{pq.y, pq.x} * f32x2{r4, r4};
+            const f32x2 kq[2] = {d2[1] * rq, d2[0] * rq};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int sj = s + 2 * j;
+              const f32x2 w2 = {W[v][sj >> 4][sj & 15], W[v][sj >> 4][(sj & 15) + 1]};
+              const f32x2 kw2 = kq[j] * w2;
+              is2 += kw2;
+              gs2[v] = __builtin_elementwise_fma(t2[j] * kq[j], kw2, gs2[v]);
+            }
+#if HG_BWD_SCHED_BARRIER
+            if ((s & 7) == 4) __builtin_amdgcn_sched_barrier(0);
+#endif
+          }
+        } else
 #pragma unroll
         for (int s = 0; s < NS; s += 2) {
           const f32x2 kf2 = {-(float)beta0(s), -(float)beta0(s + 1)};
@@ -2067,6 +2224,14 @@ bool fwd_share_rcp_ok(const DevParams &d) {
   return den * den * den * den < 1e30;
 }
 
+bool bwd_share_rcp_ok(const DevParams &d) {      // the same product-of-four-denominators condition; HG_BWD_SHARE_RCP=0: A/B
+  static const bool enabled = [] { const char *e = getenv("HG_BWD_SHARE_RCP"); return !(e && e[0] == '0'); }();
+  if (!enabled) return false;
+  const double bmax = fabs(d.lo) > fabs(d.hi) ? fabs(d.lo) : fabs(d.hi);
+  const double tmax = (13.9 + bmax) * d.inv_sigma_x, den = 1.0 + tmax * tmax;
+  return den * den * den * den < 1e30;
+}
+
 template <int T, int METHOD, bool GREEN>
 int launch_fwd_tmg(const DevParams &d, const Plan &pl, bool sym, const float *x, float *slabs, double *slab_tot,
                    hipStream_t st) {
@@ -2109,6 +2274,13 @@ int launch_bwd_tm(const DevParams &d, const Plan &pl, const float *x, const floa
                   const float *sums, float *gdst, hipStream_t st) {
   const dim3 grid(pl.S_bwd, d.B), block(256);
   const size_t lds = (size_t)3 * pl.BLK * (pl.BLK + 1) * sizeof(float);
+  if constexpr (METHOD == HG_METHOD_INVERSE_QUADRATIC) {
+    if (!d.green && bwd_share_rcp_ok(d)) {
+      hipLaunchKernelGGL((k_hist_bwd<T, METHOD, false, true>), grid, block, lds, st, d, x, gout, hist, sums, gdst, pl.rounds);
+      HG_LAUNCH_CHECK();
+      return HG_OK;
+    }
+  }
   if (d.green) hipLaunchKernelGGL((k_hist_bwd<T, METHOD, true>), grid, block, lds, st, d, x, gout, hist, sums, gdst, pl.rounds);
   else hipLaunchKernelGGL((k_hist_bwd<T, METHOD, false>), grid, block, lds, st, d, x, gout, hist, sums, gdst, pl.rounds);
   HG_LAUNCH_CHECK();

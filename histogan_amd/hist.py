@@ -4,6 +4,7 @@ Host-side mirror of histogram_classes/RGBuvHistBlock.py:75-228 (forward) and of 
 replay of it; Hellinger loss of histoGAN/histoGAN.py:957-960.  PyTorch is used only for device
 memory (caching allocator), the current stream and autograd plumbing.
 """
+import os
 import ctypes
 
 import numpy as np
@@ -13,7 +14,7 @@ from . import _lib
 from ._lib import HgHistParams, check, lib, on_device, raw_stream
 
 _IDX_CACHE = {}
-PROJ_CACHE = __import__('os').environ.get('HG_PROJ_CACHE', '1') != '0'   # A/B switch of the forward->backward projection cache
+PROJ_CACHE = os.environ.get('HG_PROJ_CACHE', '1') != '0'   # A/B switch of the forward->backward projection cache
 
 
 def _sampling_idx(size, h, device):
@@ -238,7 +239,7 @@ class _GlobalHellinger(torch.autograd.Function):
         return g * ctx.scale, None, None
 
 
-HELLINGER_LOCAL = __import__('os').environ.get('HG_HELLINGER_LOCAL', '0') != '0'
+HELLINGER_LOCAL = os.environ.get('HG_HELLINGER_LOCAL', '0') != '0'
 
 
 def hellinger_loss(target_hist, gen_hist, alpha=1.0, global_batch=None):

@@ -13,6 +13,7 @@ execution plan:
   implicit-GEMM kernels through autograd Functions that are differentiable to any order (the gradient
   penalty, reference :156-163, needs the second); LeakyReLU / residual add / Linear stay torch ops.
 """
+import os
 from math import log2
 
 import torch
@@ -46,7 +47,7 @@ def _noise_t(inoise):
     return nzt
 
 
-STYLES_AHEAD = __import__('os').environ.get('HG_STYLES_AHEAD', '1') != '0'
+STYLES_AHEAD = os.environ.get('HG_STYLES_AHEAD', '1') != '0'
 _aux_streams = {}
 
 
@@ -74,10 +75,7 @@ class Conv2DMod(nn.Module):
 
     def demod_coeff(self, y):
         """d[b,o] = rsqrt(sum_{i,k} (W[o,i,k] (y[b,i]+1))^2 + EPS)   (reference :427-429)."""
-        if self.weight.is_cuda:
-            return ops.demod_coeff(y, self.weight)
-        wsq = self.weight.pow(2).sum(dim=(2, 3))
-        return torch.rsqrt(torch.mm((y + 1).pow(2), wsq.t()) + EPS)
+        return ops.demod_coeff(y, self.weight)        # (GPU only, like every op of this module: CPU tensors raise)
 
     def contract(self, x, y, upsample=False):
         """conv(up?(x) * (y+1), W): the dense part, shared weights."""
@@ -285,14 +283,11 @@ class DiscriminatorBlock(nn.Module):
         self.downsample = Conv2d(filters, filters, 3, padding=1, stride=2) if downsample else None
 
     def forward(self, x):
-        if x.is_cuda:
-            # conv + bias + LeakyReLU(0.2) as one launch each (== self.net(x): Conv2d, LeakyReLU, Conv2d, LeakyReLU), and the
-            # residual sum `net(x) + conv_res(x)` in the epilogue of the 1x1 conv_res launch (same value: (conv + bias) + h)
-            h = conv2d_lrelu(x, self.net[0].weight, self.net[0].bias, 0.2)
-            h = conv2d_lrelu(h, self.net[2].weight, self.net[2].bias, 0.2)
-            x = conv2d_add(x, self.conv_res.weight, self.conv_res.bias, h)
-        else:
-            x = self.net(x) + self.conv_res(x)
+        # conv + bias + LeakyReLU(0.2) as one launch each (== self.net(x): Conv2d, LeakyReLU, Conv2d, LeakyReLU), and the
+        # residual sum `net(x) + conv_res(x)` in the epilogue of the 1x1 conv_res launch (same value: (conv + bias) + h)
+        h = conv2d_lrelu(x, self.net[0].weight, self.net[0].bias, 0.2)
+        h = conv2d_lrelu(h, self.net[2].weight, self.net[2].bias, 0.2)
+        x = conv2d_add(x, self.conv_res.weight, self.conv_res.bias, h)
         if self.downsample is not None:
             x = self.downsample(x)
         return x

@@ -4,6 +4,7 @@ modulate            [bilinear x2 ->] x*(s+1)             prologue of Conv2DMod  
 demod_noise_lrelu   lrelu(conv*d + noise)                epilogue               (histoGAN/histoGAN.py:427-429, 465-476)
 upsample2x          nn.Upsample(bilinear, x2) of the RGB skip                   (histoGAN/histoGAN.py:377-378)
 """
+import os
 import ctypes
 
 import torch
@@ -11,9 +12,9 @@ import torch
 from ._lib import check, lib, on_device, raw_stream
 
 
-KEEP_CONV = __import__('os').environ.get('HG_DNL_KEEP_CONV', '1') != '0'
-SKINNY_SPLIT = __import__('os').environ.get('HG_SKINNY_SPLIT', '1') != '0'   # _skinny_mm: chunked bmm + sum (0: plain mm)
-FUSED_DEMOD_BWD = __import__('os').environ.get('HG_FUSED_DEMOD_BWD', '1') != '0'   # hg_demod_style_grad (0: aten ops)
+KEEP_CONV = os.environ.get('HG_DNL_KEEP_CONV', '1') != '0'
+SKINNY_SPLIT = os.environ.get('HG_SKINNY_SPLIT', '1') != '0'   # _skinny_mm: chunked bmm + sum (0: plain mm)
+FUSED_DEMOD_BWD = os.environ.get('HG_FUSED_DEMOD_BWD', '1') != '0'   # hg_demod_style_grad (0: aten ops)
 
 
 def _st(t):

@@ -53,21 +53,16 @@ class EncoderBlock(nn.Module):
 
     def forward(self, x):
         res = self.conv_res(x)
-        if x.is_cuda:
-            # == self.net(x): Conv2d, InstanceNorm2d(affine=False, eps), LeakyReLU(0.2), twice
-            x = reops.instnorm_lrelu(self.net[0](x), self.net[1].eps, 0.2)
-            x = reops.instnorm_lrelu(self.net[3](x), self.net[4].eps, 0.2)
-        else:
-            x = self.net(x)
+        # == self.net(x): Conv2d, InstanceNorm2d(affine=False, eps), LeakyReLU(0.2), twice
+        x = reops.instnorm_lrelu(self.net[0](x), self.net[1].eps, 0.2)
+        x = reops.instnorm_lrelu(self.net[3](x), self.net[4].eps, 0.2)
         x = x + res
         return self.downsample(x), x
 
 
 def _conv_lrelu(seq, x):
     """Sequential(Conv2d, LeakyReLU(0.2)) as one launch."""
-    if x.is_cuda:
-        return conv2d_lrelu(x, seq[0].weight, seq[0].bias, 0.2)
-    return seq(x)
+    return conv2d_lrelu(x, seq[0].weight, seq[0].bias, 0.2)
 
 
 class DecoderBlock(nn.Module):
@@ -97,8 +92,7 @@ class DecoderBlock(nn.Module):
         rgb = self.conv_out_rgb(x)
         if prev_rgb is not None:
             rgb = rgb + prev_rgb
-        up = ops.upsample2x if x.is_cuda else self.upsample
-        return up(x), up(rgb)
+        return ops.upsample2x(x), ops.upsample2x(rgb)
 
 
 class RecoloringEncoderDecoder(nn.Module):

@@ -46,7 +46,8 @@ class ReplayRng:
         return self._t(self.pl)
 
 
-def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hist_kw=None, optimizer=True, d_override=None):
+def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hist_kw=None, optimizer=True, d_override=None,
+                      split_d=False):
     """sd0: GAN.state_dict() before the step (any device / dtype; moved to rng's).  batches: [D-phase batch, G-phase
     batch] of {'images', 'histograms'}.  gp / pl: gradient-penalty / path-length step.  Returns a dict with the loss
     values, the gradients {('D', name): g, ('G', name): g, ...} and (optimizer=True) the updated parameters.
@@ -97,8 +98,19 @@ def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hi
         d_loss = d_loss + gpv
         out['gp'] = float(gpv)
     dk = list(sD.keys())
+    if split_d:
+        # The hinge's two halves separately: d_scale = |gradient of the real half (+ penalty)| + |gradient of the fake half|.
+        # With every sample inside the hinge the logit gradients are +1/2B (real) and -1/2B (fake), and a bias gradient --
+        # a plain sum of the back-propagated signal over batch and pixels -- is the difference of two nearly equal halves:
+        # its fp32 error is a multiple of eps * d_scale, not of eps * |gradient|.  Tests divide bias-gradient errors by
+        # max(d_scale) (the un-cancelled magnitude) instead of max |gradient|.
+        real_part = F.relu(1 + real_out).mean() + (gpv if gp else 0.0)
+        g_r = torch.autograd.grad(real_part, [sD[k] for k in dk], retain_graph=True)
+        g_f = torch.autograd.grad(F.relu(1 - fake_out).mean(), [sD[k] for k in dk], retain_graph=True)
+        out['d_scale'] = {k: float((a.abs() + b.abs()).max()) for k, a, b in zip(dk, g_r, g_f)}
+        del g_r, g_f
     dgr = torch.autograd.grad(d_loss, [sD[k] for k in dk])
-    out['d_loss'] = float(div)
+    out['d_loss'] = float(div.detach())
     grads = {('D', k): g.detach() for k, g in zip(dk, dgr)}
     if optimizer:
         diffgrad({k: sD[k] for k in dk}, dgr)
@@ -106,6 +118,8 @@ def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hi
     if d_override is not None:
         sD = {k: cvt(d_override[k]).clone().requires_grad_(True) for k in sD}
     del fake_out, real_out, div, d_loss, dgr
+    if gp:
+        del gpv
     # ---- G phase (:934-989), against the UPDATED discriminator
     style = rng.mixed_list(B, L - 2, LAT); noise = rng.image_noise(B, S_)
     tgt = cvt(batches[1]['histograms'])
@@ -134,25 +148,6 @@ def oracle_train_step(sd0, batches, rng, L, HB, alpha, lr, gp, pl, pl_mean=0, hi
     out['grads'] = grads
     out['params'] = {(p, k): v.detach() for p, s in [('D', out['params_d'])] + groups for k, v in s.items()}
     return out
-
-
-def oracle_d_phase_fakes(sd0, batch, rng, L):
-    """The generator output the D phase of `oracle_train_step` scores (reference :899-903), evaluated with `rng`'s dtype on
-    its device -- consumes the same draws (two latents, one image noise) as the step's D phase.  Used to pick latents whose
-    fakes keep every discriminator pre-activation clear of zero (lrelu_margin), as the real images are picked."""
-    from oracle import histogan_nets as N
-    dev, dt = rng.dev, rng.dtype
-    cvt = lambda t: t.detach().to(dev).to(dt)
-    sub = lambda p: {k[len(p) + 1:]: cvt(v) for k, v in sd0.items() if k.startswith(p + '.') and v.dtype.is_floating_point}
-    sG, sS, sH = sub('G'), sub('S'), sub('H')
-    B = batch['images'].shape[0]
-    LAT = sG['blocks.0.to_style1.weight'].shape[1]
-    with torch.no_grad():
-        style = rng.mixed_list(B, L - 2, LAT)
-        noise = rng.image_noise(B, batch['images'].shape[-1])
-        w = [(N.vectorizer(sS, z, 'net'), n) for z, n in style]
-        hw = N.vectorizer(sH, cvt(batch['histograms']), 'fcs')[:, None, :]
-        return N.generator(sG, N.styles_def_to_tensor(w), torch.cat((hw, hw), 1), noise, L)
 
 
 def lrelu_margin(sd_d, images, nblk):
@@ -218,7 +213,8 @@ class LreluMasks:
     5 of 8 draws).  That is a property of fp32, not an arithmetic error, and it makes a max-norm gradient bar a coin toss.
     So the oracle is evaluated on the SAME branches: `masks` (out > 0 of every feature-map LeakyReLU of the run under
     test, in call order) replace the oracle's own sign decisions; what is left is arithmetic error.  `flips` counts the
-    disagreeing elements and `flip_margin` the largest |pre| / max|pre| among them (they must all be rounding-sized)."""
+    disagreeing elements and `flip_margin` the largest |pre| / max|pre| among them (they must all be rounding-sized).
+    A `None` entry (and every call past the end of the list) keeps the oracle's own decisions for that call."""
 
     def __init__(self, masks):
         self.masks, self.k, self.flips, self.flip_margin, self.total = list(masks), 0, 0, 0.0, 0
@@ -230,8 +226,10 @@ class LreluMasks:
         def hooked(x):
             if x.dim() != 4:
                 return self._orig(x)
-            m = self.masks[self.k]
+            m = self.masks[self.k] if self.k < len(self.masks) else None
             self.k += 1
+            if m is None:                # no recorded branch decisions for this call: the oracle's own
+                return self._orig(x)
             assert m.shape == x.shape, (m.shape, x.shape)
             own = x.detach() > 0
             diff = own != m

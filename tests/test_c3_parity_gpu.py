@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import ROOT, relmax
-from oracle_step import ReplayRng, lrelu_margin, oracle_d_phase_fakes, oracle_train_step
+from oracle_step import ReplayRng, lrelu_margin, oracle_train_step
 
 pytestmark = pytest.mark.gpu
 
@@ -259,30 +259,51 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
         if margin > 5e-8:
             break
     assert margin > 5e-8, margin
-    # ... and, on the plain step (where the fakes' half of the hinge carries gradients into D), latents whose fakes do too
+    # The fake half of the plain step's hinge cannot be selected that way: the discriminator sees OUR fp32 generator output,
+    # which differs from the fp64 one by ~5e-7, so pre-activations within ~1e-6 of zero (there are always a few among
+    # 7.9 M) take the other LeakyReLU slope, and one such pixel moves its layer's weight / bias gradient by 2.5e-3 (measured:
+    # blocks.3.net.2).  As in the generator test the fp64 oracle therefore scores the fakes ON THE BRANCHES OUR FORWARD
+    # TOOK (oracle_step.LreluMasks; the disagreeing elements are counted and must be rounding-sized).
     rng_seed, fake_margin = 78, None
-    if not gp:
-        for rng_seed in range(78, 118):
-            fakes = oracle_d_phase_fakes(sd0, batches[0], ReplayRng(dev, B, L, LAT, S_, rng_seed, tt=2, dtype=torch.float64), L)
-            fake_margin = lrelu_margin(sd_d, fakes, L + 1)
-            if fake_margin > 5e-8:
-                break
-        assert fake_margin > 5e-8, fake_margin
     tr.loader = iter(batches)
     tr.rng = ReplayRng(dev, B, L, LAT, S_, rng_seed, tt=2)
+    from histogan_amd import nets as HN
+    d_masks, orig_cl = [], HN.conv2d_lrelu
+
+    def recording_cl(*a, **k):
+        out = orig_cl(*a, **k)
+        d_masks.append(out.detach() > 0)
+        return out
+
+    HN.conv2d_lrelu = recording_cl
     tr.steps = step_no
-    tr.train(alpha=ALPHA)
+    try:
+        tr.train(alpha=ALPHA)
+    finally:
+        HN.conv2d_lrelu = orig_cl
     new = {k: v.detach() for k, v in GAN.state_dict().items()}
+    # 4-D LeakyReLU calls of the oracle step in order: generator (no-grad) 2 per block, D(fake) 2 per block, D(real), then
+    # the G phase.  Plain step: our D phase is ONE pass over [fake; real] -- its first 2 * (L + 1) recorded masks, fake half.
+    n_g, n_d = 2 * L, 2 * (L + 1)
+    mask_list = None
+    if not gp:
+        assert len(d_masks) == 2 * n_d and d_masks[0].shape[0] == 2 * B, (len(d_masks), d_masks[0].shape)
+        mask_list = [None] * n_g + [m[:B] for m in d_masks[:n_d]]
 
     # the G phase of both oracle runs scores the fakes with the discriminator the product path used (see oracle_step.py:
     # the first DiffGrad step is sign-like, its result ill-conditioned wherever a gradient is rounding noise)
     d_used = {k[2:]: v for k, v in new.items() if k.startswith('D.')}
-    truth = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, rng_seed, tt=2, dtype=torch.float64), L, HB, ALPHA,
-                              LR, gp, pl, d_override=d_used)
+    from oracle_step import LreluMasks
+    with LreluMasks(mask_list or []) as lm:
+        truth = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, rng_seed, tt=2, dtype=torch.float64), L, HB, ALPHA,
+                                  LR, gp, pl, d_override=d_used, split_d=True)
+    if not gp:
+        fake_margin = lm.flip_margin
+        assert lm.flips <= 1e-5 * lm.total and lm.flip_margin <= 5e-6, (lm.flips, lm.total, lm.flip_margin)
     ref32 = oracle_train_step(sd0, batches, ReplayRng(dev, B, L, LAT, S_, rng_seed, tt=2), L, HB, ALPHA, LR, gp, pl,
                               d_override=d_used)
     rel = lambda a, b: abs(a - b) / max(1.0, abs(b))      # the un-normalised logits are >> 1 at this capacity
-    rec = dict(data_seed=data_seed, lrelu_margin=margin, rng_seed=rng_seed, lrelu_margin_fakes=fake_margin, d_loss=rel(tr.d_loss, truth['d_loss']), g_loss=rel(tr.g_loss, truth['g_loss']),
+    rec = dict(data_seed=data_seed, lrelu_margin=margin, rng_seed=rng_seed, lrelu_flips_fakes=lm.flips, lrelu_flip_margin_fakes=fake_margin, d_loss=rel(tr.d_loss, truth['d_loss']), g_loss=rel(tr.g_loss, truth['g_loss']),
                h_loss=abs(tr.h_loss - truth['h_loss']), values=dict(d=truth['d_loss'], g=truth['g_loss'], h=truth['h_loss']),
                g_loss_ref32=rel(ref32['g_loss'], truth['g_loss']))
     assert rec['d_loss'] <= 1e-4 and rec['g_loss'] <= 1e-4 and rec['h_loss'] <= 1e-4, rec
@@ -299,15 +320,17 @@ def test_c3_train_step_matches_oracle(step_no, gpu_device, tmp_path):
     # gradient-penalty steps they are the penalty's second-order terms through the LeakyReLU masks (the data above keeps
     # every pre-activation clear of zero, so fp32 and fp64 evaluations take the same slopes): 1e-4 per tensor.
     worst_d, off, od, rd = (-1.0, ''), 0, [], []
-    # (with every sample inside the hinge the logit gradients are +1/2B on the real and -1/2B on the fake half: they sum to
-    # zero, so the gradients of to_logit.bias and of the last block's conv_res.bias -- linear paths into the logit -- vanish
-    # identically in exact arithmetic; such a tensor is held to the scale of the other bias gradients instead of its own)
+    # Bias gradients are judged against their UN-CANCELLED magnitude (oracle_step: d_scale = |real half| + |fake half|): with
+    # every sample inside the hinge the two halves of a bias gradient nearly cancel (to_logit.bias and the last block's
+    # conv_res.bias cancel identically), and any fp32 evaluation -- ours, aten's -- carries an error proportional to the
+    # halves, not to their difference (measured: blocks.3.net.2.bias 2.7e-3 of its own maximum for ours, 1e-3 .. 2e-2 for
+    # aten / MIOpen from box to box).  Weight gradients keep their own maximum as the denominator.
     bias_scale = max(float(t.abs().max()) for pk, t in truth['grads'].items() if pk[0] == 'D' and pk[1].endswith('bias'))
     def rel_d(a, t, name):
         a, t = a.double(), t.double()
         den = float(t.abs().max())
         if name.endswith('bias'):
-            den = max(den, 1e-3 * bias_scale)
+            den = max(den, truth['d_scale'][name], 1e-3 * bias_scale)
         return float((a - t).abs().max()) / max(den, 1e-300)
     for prm in GAN._flat_d.params:
         n = prm.numel()
@@ -380,7 +403,7 @@ def test_c3_networks_match_reference_golden(gpu_device):
     hists = torch.randn(B, 2, LAT, generator=gen).to(dev).requires_grad_(True)
     noise = torch.rand(B, S_, S_, 1, generator=gen).to(dev)
     go = torch.randn(B, 3, S_, S_, generator=gen).to(dev)
-    img = torch.rand(B, 3, S_, S_, generator=gen).to(dev)
+    img = torch.rand(B, 3, S_, S_, generator=torch.Generator(device='cpu').manual_seed(int(g['img_seed']))).to(dev)
     rec = {}
 
     def check_grads(prefix, names, grads, seed0):

@@ -92,3 +92,42 @@ def test_c5_reduced_width_step_matches_oracle(gpu_device, tmp_path):
     for name in ('to_logit.weight', 'attn_blocks.2.0.fn.fn.to_q.weight', 'attn_blocks.3.1.fn.fn.to_out.weight', 'blocks.9.net.0.weight'):
         e_o, e_r = _rel(grads[name], truth['grads'][('D', name)]), _rel(ref32['grads'][('D', name)], truth['grads'][('D', name)])
         assert e_o <= max(2e-4, 3 * e_r), (name, e_o, e_r)
+
+
+def test_c5_full_width_two_steps(gpu_device, tmp_path):
+    """BASELINE.json configs[4] AT FULL WIDTH on one GPU: 1024^2, network_capacity 16 (8 192-channel
+    layers, 1.24 G + 1.45 G parameters), batch 8, h = 128 (the plane-at-a-time histogram backward), discriminator attention
+    after blocks 3 and 4 -- two Trainer.train() steps (step 0: gradient penalty + path length; step 1: plain, one [fake; real]
+    pass of 16 images).  ~120 GB of HBM.  Checks what can be checked without an oracle at this size: the convolution plans of
+    the 8 192-channel layers, the batch-sliced >= 2^31-element activations and the 2.7 G-parameter packing / optimizer
+    launches all run; losses are finite; every parameter tensor of G and D received a finite, non-zero gradient; the
+    histogram loss is that of normalised histograms (0 <= h_loss <= alpha)."""
+    from histoGAN import Trainer
+    if torch.cuda.get_device_properties(gpu_device).total_memory < 200 * 2 ** 30:
+        pytest.skip('needs ~120 GB of device memory')
+    tr = Trainer('c5full', tmp_path / 'r', tmp_path / 'm', 1024, 16, batch_size=8, hist_bin=128, hist_insz=150,
+                 hist_resizing='interpolation', attn_layers=[3, 4])
+    tr.run_evaluate = tr.run_save = False
+    tr.graph_mode = '0'
+    tr.set_synthetic_data_src(pool=1)
+    tr.train(alpha=2)
+    tr.train(alpha=2)
+    torch.cuda.synchronize()
+    assert tr.steps == 2
+    for v in (tr.d_loss, tr.g_loss, tr.h_loss, tr.last_gp_loss):
+        assert np.isfinite(v), (tr.d_loss, tr.g_loss, tr.h_loss, tr.last_gp_loss)
+    assert 0.0 <= tr.h_loss <= 2.0 + 1e-3
+    n_g = sum(p.numel() for p in tr.GAN.G.parameters())
+    n_d = sum(p.numel() for p in tr.GAN.D.parameters())
+    assert n_g > 1.2e9 and n_d > 1.4e9, (n_g, n_d)
+    # generator-side gradients of the last step are still in the flat buffer (zeroed at the start of the next step)
+    fg = tr.GAN._flat_g
+    assert bool(torch.isfinite(fg.grad).all())
+    off = 0
+    for prm in fg.params:
+        n = prm.numel()
+        if n >= 4096:                                    # every weight matrix / convolution weight of G, S, H
+            assert float(fg.grad[off:off + n].abs().max()) > 0, tuple(prm.shape)
+        off += n
+    del tr
+    torch.cuda.empty_cache()

@@ -267,7 +267,7 @@ def test_plain_step_d_phase_matches_oracle(gpu_device, tmp_path):
     cpu = torch.device('cpu')
     ref = oracle_train_step(sd0, batches, ReplayRng(cpu, B, L, LAT, S_, 79), L, HB, ALPHA, LR, False, False)
     truth = oracle_train_step(sd0, batches, ReplayRng(cpu, B, L, LAT, S_, 79, dtype=torch.float64), L, HB, ALPHA, LR,
-                              False, False)
+                              False, False, split_d=True)
     assert truth['d_loss'] > 0.1, truth['d_loss']            # non-vacuous
     assert abs(tr.d_loss - truth['d_loss']) <= 1e-4
     off = 0
@@ -277,11 +277,12 @@ def test_plain_step_d_phase_matches_oracle(gpu_device, tmp_path):
         name = next(k for k, v in GAN.D.named_parameters() if v is prm)
         mine = GAN._flat_d.grad[off:off + n].view(prm.shape).detach().cpu().double()
         t = truth['grads'][('D', name)]
-        # (every sample inside the hinge: the logit gradients +-1/2B sum to zero, so to_logit.bias and the last block's
-        # conv_res.bias -- linear paths into the logit -- have identically zero gradients; held to the other biases' scale)
+        # (every sample inside the hinge: the logit gradients +-1/2B sum to zero, so the real and the fake half of a bias
+        # gradient nearly cancel -- identically for to_logit.bias and the last block's conv_res.bias; bias gradients are
+        # held to their un-cancelled magnitude, oracle_step: d_scale)
         den = float(t.abs().max())
         if name.endswith('bias'):
-            den = max(den, 1e-3 * bias_scale)
+            den = max(den, truth['d_scale'][name], 1e-3 * bias_scale)
         else:
             assert den > 0, name
         e_o = float((mine - t).abs().max()) / den

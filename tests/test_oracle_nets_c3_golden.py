@@ -39,7 +39,7 @@ def c3():
     S_, CAP, LAT, B, L, _ = [int(v) for v in g['meta']]
     inputs = dict(styles=torch.randn(B, L - 2, LAT, generator=gen), hists=torch.randn(B, 2, LAT, generator=gen),
                   noise=torch.rand(B, S_, S_, 1, generator=gen), go=torch.randn(B, 3, S_, S_, generator=gen),
-                  img=torch.rand(B, 3, S_, S_, generator=gen))
+                  img=torch.rand(B, 3, S_, S_, generator=torch.Generator(device='cpu').manual_seed(int(g['img_seed']))))
     return g, mk, sds, inputs
 
 

@@ -1,7 +1,15 @@
 #!/usr/bin/env python3
-"""Debug: is the GP-step mismatch of the C3 parity test a LeakyReLU mask flip?  Same seeds as the test: compare the sign of
-every LeakyReLU output of the discriminator (our fp32 kernels vs fp64 torch) on the test's real batch, and report the fp64
-pre-activation magnitude at every flipped element relative to the layer's largest."""
+"""LeakyReLU mask flips between an fp32 evaluation and fp64 (how DESIGN.md section 0's finding was made; replaces round 3's
+tools/debug_gp*.py).  A pre-activation within fp32 rounding of zero gets the other LeakyReLU slope in ANY fp32 evaluation
+than in fp64; at B = 2 one such pixel moves a small weight-gradient tensor by 1e-2 through the gradient penalty's
+second-order terms.  The parity tests therefore pick input data whose closest pre-activation is clear of zero
+(tests/oracle_step.lrelu_margin) or compare on the branches the forward took (oracle_step.LreluMasks).
+
+    python tools/lrelu_margin_probe.py [data_seed]        # on the GPU box
+
+Same set-up as tests/test_c3_parity_gpu.py (256^2, capacity 16, B = 2, seed 31): compares the sign of every LeakyReLU output
+of the discriminator (our fp32 kernels vs fp64 torch) on the batch of `data_seed` and reports the fp64 pre-activation
+magnitude at every flipped element relative to the layer's largest."""
 import os
 import sys
 import tempfile
@@ -23,7 +31,7 @@ tr = Trainer('dbg', tmp + '/r', tmp + '/m', S_, CAP, batch_size=B, lr=2e-4, hist
              hist_resizing='interpolation', mixed_prob=1.1)
 tr.init_GAN()
 D = tr.GAN.D
-gen = torch.Generator().manual_seed(6)
+gen = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 6)
 img = torch.rand(B, 3, S_, S_, generator=gen).to(dev)
 sd = {k: v.detach().double() for k, v in D.state_dict().items()}
 x32, x64 = img.clone(), img.double()

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r03_pmc_traffic.json from the traffic.txt files of tools/conv_traffic.sh (roofline conv + wgrad + dense
+"""profiles/r04_pmc_traffic.json from the traffic.txt files of tools/conv_traffic.sh (roofline conv + wgrad + dense
 histogram kernels) and tools/hist_traffic.sh with HG_HIST_METHOD=thresholding: FETCH_SIZE / WRITE_SIZE (KB, separate
 passes) per launch, with the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md for 16-byte-per-lane streams
 (FETCH_SIZE reports half), stamped with the digest of the kernel source they were measured on -- bench.py reports
@@ -70,9 +70,14 @@ for name in ('k_thr_fwd_lean', 'k_hist_finish', 'k_thr_bwd_lean'):
         tot += 2 * v['FETCH_SIZE'] * 1024 + v['WRITE_SIZE'] * 1024
 t['total_fabric_bytes_fwd_bwd'] = tot
 t['algorithmic_bytes_fwd_bwd'] = 78643200
+# the same total where bench.py looks for it: digest-guarded like the other launches (round 3 kept it in r03_recorded.json without one)
+bench['thr_fwd_bwd_c2'] = dict(fetch_bytes=sum(v['fetch_bytes_corrected'] for v in t.values() if isinstance(v, dict)),
+                               write_bytes=sum(v['write_bytes'] for v in t.values() if isinstance(v, dict)),
+                               comment='k_thr_fwd_lean + k_hist_finish + k_thr_bwd_lean, 16-byte-per-lane streams: FETCH_SIZE x 2',
+                               source='hg_hist.hip', source_sha16=digest('hg_hist.hip'), commit=commit)
 rec = dict(_note='rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes), per launch, counter unit KB; FETCH_SIZE '
                  'doubled for 16-byte-per-lane streams per /opt/skills/guides/MI355X_MICROARCH.md (HBM section); Infinity-Cache hits '
                  'are counted (fabric traffic: an upper bound on HBM traffic)', thresholding_b32_256x256_h64=t, bench=bench)
-with open(os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json'), 'w') as f:
+with open(os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json'), 'w') as f:
     json.dump(rec, f, indent=1)
 print(json.dumps(rec, indent=1)[:1200])
