@@ -37,6 +37,12 @@ class HgHistParams(ctypes.Structure):
     ]
 
 
+class GlinLayer(ctypes.Structure):
+    """struct hg_glin_layer (include/hg_linear.h)."""
+    _fields_ = [('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('b', ctypes.c_void_p), ('y', ctypes.c_void_p),
+                ('gw', ctypes.c_void_p), ('gb', ctypes.c_void_p), ('N', ctypes.c_int32), ('group', ctypes.c_int32)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -140,6 +146,16 @@ def _load():
     lib.hg_stencil3.argtypes = [vp, vp, ctypes.POINTER(f32), i32, i32, i32, i32, i32, vp]
     lib.hg_depthwise_valid.restype = ctypes.c_int
     lib.hg_depthwise_valid.argtypes = [vp, vp, vp, i64, i32, i32, i32, i32, vp]
+    # include/hg_linear.h
+    GL = ctypes.POINTER(GlinLayer)
+    lib.hg_grouped_linear_fwd.restype = ctypes.c_int
+    lib.hg_grouped_linear_fwd.argtypes = [GL, i32, i32, i32, vp]
+    lib.hg_grouped_linear_bwd_input_workspace_bytes.restype = sz
+    lib.hg_grouped_linear_bwd_input_workspace_bytes.argtypes = [GL, i32, i32, i32]
+    lib.hg_grouped_linear_bwd_input.restype = ctypes.c_int
+    lib.hg_grouped_linear_bwd_input.argtypes = [GL, i32, ctypes.POINTER(vp), i32, i32, i32, vp, sz, vp]
+    lib.hg_grouped_linear_bwd_params.restype = ctypes.c_int
+    lib.hg_grouped_linear_bwd_params.argtypes = [GL, i32, i32, i32, vp]
     # include/hg_augment.h
     lib.hg_augment_spatial.restype = ctypes.c_int
     lib.hg_augment_spatial.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
@@ -154,7 +170,7 @@ def _load():
 
 lib = _load()
 
-# every symbol include/hg_hist.h, hg_nets.h, hg_conv.h, hg_recolor.h and hg_augment.h declare
+# every symbol include/hg_hist.h, hg_nets.h, hg_conv.h, hg_recolor.h, hg_augment.h and hg_linear.h declare
 EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_uses_proj_cache', 'hg_rgbuv_hist_fwd',
            'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd', 'hg_selftest_fastlog',
            'hg_modulate_fwd', 'hg_modulate_bwd', 'hg_demod_noise_lrelu_fwd', 'hg_demod_noise_lrelu_bwd',
@@ -164,7 +180,8 @@ EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg
            'hg_conv2d_wgrad', 'hg_conv_b6_packed_bytes', 'hg_conv_b6_pack_weights', 'hg_conv2d_b6', 'hg_conv2d_b9',
            'hg_instnorm_workspace_bytes', 'hg_instnorm_lrelu_fwd', 'hg_instnorm_lrelu_bwd', 'hg_stencil3',
            'hg_depthwise_valid', 'hg_augment_spatial', 'hg_augment_workspace_bytes', 'hg_sample_mean',
-           'hg_augment_color')
+           'hg_augment_color', 'hg_grouped_linear_fwd', 'hg_grouped_linear_bwd_input_workspace_bytes',
+           'hg_grouped_linear_bwd_input', 'hg_grouped_linear_bwd_params')
 
 
 class HgError(RuntimeError):

@@ -198,6 +198,29 @@ class Generator(nn.Module):
         styles = torch.cat((styles.transpose(0, 1), hists.transpose(0, 1)), dim=0)
         _noise_t(input_noise)
         rgb = None
+        layers = [m for block in self.blocks for m in (block.to_style1, block.to_style2, block.to_rgb.to_style)]
+        if styles.dtype == torch.float32 and ops.grouped_linear_supported([styles[0]], [m.weight for m in layers]):
+            # The 21 style projections (three nn.Linear(512, C) per block on the block's style vector) as ONE launch
+            # (include/hg_linear.h) instead of 21 library GEMMs of 32 ... 64 workgroups -- and 3 launches instead of 42 GEMMs +
+            # 21 bias reductions + the gradient sums in the backward.  Without autograd they still run beside the head of the
+            # chain on the second stream.
+            groups = [i for i in range(len(self.blocks)) for _ in range(3)]
+            xs = [styles[i] for i in range(len(self.blocks))]
+            ahead = (STYLES_AHEAD and not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing())
+            if ahead:
+                main, aux = torch.cuda.current_stream(styles.device), aux_stream(styles.device)
+                aux.wait_event(main.record_event())
+                with torch.cuda.stream(aux):
+                    t = ops.grouped_linear(xs, layers, groups)
+                main.wait_stream(aux)
+                for u in t:
+                    u.record_stream(main)
+                styles.record_stream(aux)
+            else:
+                t = ops.grouped_linear(xs, layers, groups)
+            for i, block in enumerate(self.blocks):
+                x, rgb = block.forward_(x, rgb, t[3 * i], t[3 * i + 1], t[3 * i + 2], inoise=input_noise)
+            return rgb
         if (STYLES_AHEAD and styles.is_cuda and not torch.is_grad_enabled()
                 and not torch.cuda.is_current_stream_capturing()):
             # Without autograd (the D phase's generator forward, evaluate()): the 21 `to_style` projections depend on the

@@ -301,3 +301,88 @@ class _DemodCoeff(torch.autograd.Function):
 
 def demod_coeff(y, weight):
     return _DemodCoeff.apply(y, weight)
+
+
+# ---- grouped linear layers (include/hg_linear.h): the generator's 21 style projections as one launch per pass ----------
+GROUPED_STYLES = os.environ.get('HG_GROUPED_STYLES', '1') != '0'   # 0: one F.linear (library GEMM) per projection
+
+
+def _glin_table(xs, ws, bs, ys, groups, gws=None, gbs=None):
+    from ._lib import GlinLayer
+    n = len(ws)
+    tab = (GlinLayer * n)()
+    for i in range(n):
+        t = tab[i]
+        t.x, t.w, t.y = xs[groups[i]].data_ptr(), ws[i].data_ptr(), ys[i].data_ptr()
+        t.b = bs[i].data_ptr() if bs is not None and bs[i] is not None else None
+        t.gw = gws[i].data_ptr() if gws is not None else None
+        t.gb = gbs[i].data_ptr() if gbs is not None and gbs[i] is not None else None
+        t.N, t.group = ws[i].shape[0], groups[i]
+    return tab
+
+
+def grouped_linear_supported(xs, ws):
+    B, K = xs[0].shape
+    return (GROUPED_STYLES and xs[0].is_cuda and B <= 64 and K % 32 == 0 and len(ws) <= 32
+            and all(w.shape[0] % 4 == 0 and w.shape[1] == K for w in ws))
+
+
+class _GroupedLinear(torch.autograd.Function):
+    """y_l = x_g(l) @ W_l^T + b_l for a list of nn.Linear layers whose inputs come in groups (histoGAN/histoGAN.py:372, 450,
+    454: to_style1 / to_style2 / to_rgb.to_style of one generator block share the block's style vector).  ONE launch
+    forward (hg_grouped_linear_fwd), three backward (input gradients: two, parameter gradients: one)."""
+
+    @staticmethod
+    def forward(ctx, groups, n_groups, *tensors):
+        xs = [t.detach().contiguous() for t in tensors[:n_groups]]
+        n = (len(tensors) - n_groups) // 2
+        ws = [t.detach() for t in tensors[n_groups:n_groups + n]]
+        bs = [t.detach() for t in tensors[n_groups + n:]]
+        B, K = xs[0].shape
+        dev = xs[0].device
+        ys = [torch.empty((B, w.shape[0]), dtype=torch.float32, device=dev) for w in ws]
+        tab = _glin_table(xs, ws, bs, ys, groups)
+        with on_device(dev):
+            check(lib.hg_grouped_linear_fwd(tab, len(ws), B, K, raw_stream(dev)), 'hg_grouped_linear_fwd')
+        ctx.groups, ctx.n_groups, ctx.n = groups, n_groups, n
+        ctx.save_for_backward(*xs, *ws)
+        return tuple(ys)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gys):
+        groups, G, n = ctx.groups, ctx.n_groups, ctx.n
+        saved = ctx.saved_tensors
+        xs, ws = list(saved[:G]), list(saved[G:])
+        B, K = xs[0].shape
+        dev = xs[0].device
+        gys = [(g.contiguous() if g is not None else torch.zeros((B, w.shape[0]), dtype=torch.float32, device=dev))
+               for g, w in zip(gys, ws)]
+        need_x = any(ctx.needs_input_grad[2:2 + G])
+        need_p = any(ctx.needs_input_grad[2 + G:])
+        gxs = [None] * G
+        gws, gbs = [None] * n, [None] * n
+        with on_device(dev):
+            st = raw_stream(dev)
+            if need_x:
+                gxs = [torch.empty_like(x) for x in xs]
+                tab = _glin_table(xs, ws, None, gys, groups)
+                nb = lib.hg_grouped_linear_bwd_input_workspace_bytes(tab, n, B, K)
+                wsb = torch.empty((max(nb, 4),), dtype=torch.uint8, device=dev)
+                ptrs = (ctypes.c_void_p * G)(*[g.data_ptr() for g in gxs])
+                check(lib.hg_grouped_linear_bwd_input(tab, n, ptrs, G, B, K, wsb.data_ptr(), wsb.numel(), st),
+                      'hg_grouped_linear_bwd_input')
+            if need_p:
+                gws = [torch.empty_like(w) for w in ws]
+                gbs = [torch.empty((w.shape[0],), dtype=torch.float32, device=dev) for w in ws]
+                tab = _glin_table(xs, ws, None, gys, groups, gws, gbs)
+                check(lib.hg_grouped_linear_bwd_params(tab, n, B, K, st), 'hg_grouped_linear_bwd_params')
+        return (None, None, *gxs, *gws, *gbs)
+
+
+def grouped_linear(xs, layers, groups):
+    """xs: list of (B, K) inputs; layers: list of nn.Linear (with bias); groups[i]: index into xs of layer i's input (non-
+    decreasing).  Returns the list of outputs."""
+    ws = [m.weight for m in layers]
+    bs = [m.bias for m in layers]
+    return list(_GroupedLinear.apply(tuple(groups), len(xs), *xs, *ws, *bs))

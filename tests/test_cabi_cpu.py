@@ -179,3 +179,25 @@ def test_pack_multi_block_table_is_consistent(L):
     assert L.lib.hg_conv_pack_blocks(0, 4) == 0
     assert L.lib.hg_conv_pack_weights_multi(None, 1, 1, None) < 0
     assert L.lib.hg_conv_pack_weights_multi(1, 0, 1, None) < 0
+
+
+def test_grouped_linear_argument_validation(L):
+    """include/hg_linear.h, host side only: table checks and the workspace query (no launch)."""
+    T = L.GlinLayer
+    def tab(*rows):
+        t = (T * len(rows))()
+        for i, (N, g) in enumerate(rows):
+            t[i].x, t[i].w, t[i].y, t[i].N, t[i].group = 0x1000, 0x2000, 0x3000, N, g
+        return t
+    q = lambda t, n, B, K: L.lib.hg_grouped_linear_bwd_input_workspace_bytes(t, n, B, K)
+    t = tab((64, 0), (2048, 0), (2048, 0), (1024, 1))
+    assert q(t, 4, 32, 512) == (1 + 16 + 16 + 8) * 32 * 512 * 4          # one slab per 128 output features
+    assert q(t, 4, 65, 512) == 0 and q(t, 4, 32, 500) == 0               # batch > 64, K not a multiple of 32: unsupported
+    assert q(tab((64, 1)), 1, 32, 512) == 0                                # groups start at 0
+    assert q(tab((64, 0), (64, 2)), 2, 32, 512) == 0                       # ... and are contiguous
+    assert q(tab((62, 0)), 1, 32, 512) == 0                                # rows of dy are read 16 bytes at a time
+    assert L.lib.hg_grouped_linear_fwd(t, 0, 32, 512, None) == -1 and L.lib.hg_grouped_linear_fwd(None, 1, 32, 512, None) == -1
+    assert L.lib.hg_grouped_linear_fwd(t, 4, 65, 512, None) == -5
+    bad = tab((64, 0)); bad[0].w = 0x2004
+    assert L.lib.hg_grouped_linear_fwd(bad, 1, 32, 512, None) == -1        # misaligned
+    assert ctypes.sizeof(T) == 56
