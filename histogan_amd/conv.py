@@ -127,6 +127,8 @@ def weights_changed(flat=None):
         for k in list(_owner_gen):
             _owner_gen[k] += 1
         _owner_gen[None] = _owner_gen.get(None, 0) + 1
+        if _pack_events and not torch.cuda.is_current_stream_capturing():
+            drain_pack_streams()
     else:
         o = _owner_of(flat)
         _owner_gen[o] = _owner_gen.get(o, 0) + 1
@@ -269,7 +271,19 @@ def prepack_async(flat):
     return ok
 
 
+def drain_pack_streams():
+    """The current stream of every device waits for its asynchronous pack stream, and the per-owner pack events are dropped:
+    called before a train-step graph is captured / replayed (a capturing stream must not wait on an event recorded outside the
+    capture) and when every cached operand is invalidated from the host (weights_changed(None): the next pack of the same
+    buffers then runs behind the one in flight)."""
+    for idx, st in _pack_streams.items():
+        torch.cuda.current_stream(torch.device('cuda', idx)).wait_stream(st)
+    _pack_events.clear()
+
+
 def _await_pack(owner, device):
+    if torch.cuda.is_current_stream_capturing():    # (drain_pack_streams() ran before the capture began)
+        return
     ent = _pack_events.get(owner)
     if ent is not None:
         cur = torch.cuda.current_stream(device)
@@ -426,6 +440,15 @@ def side_stream(device):
     return st
 
 
+def _assert_single_writer(device):
+    """Overwrite-vs-accumulate of a flat gradient slot is decided from the host-side set `direct_written` at ENQUEUE time:
+    correct only while every direct write is enqueued on ONE stream in order (the weight-gradient stream, or the capturing
+    stream with HG_GRAPH_WGRAD_INLINE).  A second writer stream would silently corrupt gradients: fail loudly instead."""
+    cur = torch.cuda.current_stream(device)
+    assert torch.cuda.is_current_stream_capturing() or cur.cuda_stream == side_stream(device).cuda_stream, \
+        'direct gradient write outside the weight-gradient stream'
+
+
 def _direct_wgrad(w, x, g, stride):
     """Weight gradient of conv(x, w) for upstream gradient g into w's flat-buffer slot; False if w has no slot (or
     a graph is being recorded): the caller then returns the gradient to autograd as usual."""
@@ -460,6 +483,7 @@ def _direct_wgrad(w, x, g, stride):
     side = side_stream(x.device)
     side.wait_event(main.record_event())             # g (and x) are ready on the main stream
     with torch.cuda.stream(side):
+        _assert_single_writer(x.device)
         if skey in flat.direct_written:
             slot.add_(conv_wgrad(xc, gc, w.shape[2], stride))
         else:
@@ -493,6 +517,7 @@ def direct_demod_weight_term(w, gd, d, s1):
     K, taps = w.shape[1], w.shape[2] * w.shape[3]
 
     def run():
+        _assert_single_writer(w.device)
         with on_device(w.device):
             check(lib.hg_demod_weight_term(w.data_ptr(), gd.data_ptr(), d.data_ptr(), s1.data_ptr(), slot.data_ptr(), B, N, K,
                                            taps, int(skey in flat.direct_written), raw_stream(w.device)),

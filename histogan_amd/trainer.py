@@ -43,13 +43,14 @@ from torch.autograd import grad as torch_grad
 
 from . import ddp
 from .augment import AugWrapper
-from .conv import enable_pack_cache, input_grads_only, prepack_async, weights_changed
+from .conv import drain_pack_streams, enable_pack_cache, input_grads_only, prepack_async, weights_changed
 from .hist import hellinger_loss
 from .nets import Discriminator, Generator, HistVectorizer, StyleVectorizer
 from .optim import DiffGrad, FlatParams, ema_update
 
 EPS = 1e-8
 EXTS = ['jpg', 'png']
+G_OVERLAP_DDP = os.environ.get('HG_G_OVERLAP_DDP', '0') == '1'   # the same under data parallelism (see _device_step)
 G_OVERLAP = os.environ.get('HG_G_OVERLAP', '1') != '0'   # G-phase generator forward on a second stream beside the D phase
 G_STREAM_PRIO = int(os.environ.get('HG_G_STREAM_PRIO', '0'))   # HIP priority of that stream (0 normal, -1 high)
 H_SIDE = os.environ.get('HG_H_SIDE', '1') != '0'               # D phase: histogram vectorizer on a second stream beside S
@@ -510,6 +511,7 @@ class Trainer():
         """One step from a captured graph; gp: the gradient-penalty variant (its own graph, same memory pool -- the two
         are never in flight together)."""
         GAN = self.GAN
+        drain_pack_streams()     # operands packed asynchronously by an eager step: ordered before the capture / replay
         gs = self._graph_inputs()
         self._fill_graph_inputs(gs)
         GAN.D_opt.prepare_replay()
@@ -612,10 +614,12 @@ class Trainer():
                 noise = self.rng.image_noise(batch_size, image_size)
             return noise, hist_batch, w_styles, h_w_space, GAN.G(w_styles, h_w_space, noise)
 
-        # (under data parallelism as well: the D-gradient all-reduce runs on RCCL's own stream beside both -- it waits for
-        # the gathered D gradients on the main stream and is waited for by D's optimizer step, neither of which the second
-        # stream's generator forward touches)
-        overlap_g = G_OVERLAP and acc == 1
+        # Under data parallelism the second-stream forward is OPT-IN (HG_G_OVERLAP_DDP=1).  Nothing it touches depends on
+        # the D-gradient all-reduce (RCCL's own stream; waited for by D's optimizer step only), but the one multi-rank set-up
+        # that can be measured here -- two gloo ranks sharing a GPU -- runs 1.73 s per step with it and 0.26 s without
+        # (profiles/r04_ddp_gloo_knobs.json: seven streams per process on one device), so the default stays round 3's
+        # until a multi-GPU node says otherwise.
+        overlap_g = G_OVERLAP and acc == 1 and (G_OVERLAP_DDP or not ddp.is_dist())
         if overlap_g and not getattr(self, '_warn_off', False):
             # parameters live on the default stream, part of the graph now runs on another one: the engine's stream
             # hand-over is intended
