@@ -227,6 +227,46 @@ def conv_kernel_times(dev, B, iters=6, layers=None):
     return out
 
 
+def leading_kernel_lines(dev, B, ct, size, cap):
+    """Stand-alone lines for the two k_conv instantiations that lead the step's kernel trace (profiles/r04_train_c3_kernel_stats.md:
+    KC = 4 / FE = false, 10.6 % of the kernel time; the fused-extras FE = true one, 8.1 %) -- the headline roofline launch is
+    the KC = 2 instantiation, only the 4th by step time.  (a) KC = 4, FE = false: the 128 x 128 tile with 4-channel K
+    chunks that the deep-K 3x3 layers take; timed at 512 -> 256 channels, 32 x 32 (at 256^2 / capacity 16) through
+    hg_conv2d_fwd (the number conv_kernel_times already measured).  (b) FE = true: the no-autograd generator stage (hg_modconv2d_fwd: modulation while staging,
+    convolution, demodulation, noise, LeakyReLU in one launch) at the roofline launch's own layer, HIP events around
+    ops.modconv_stage under no_grad."""
+    from histogan_amd import ops
+    out = []
+    key = (32 * cap, 16 * cap, size // 8)
+    if key in ct:
+        fl, tf = ct[key][0], ct[key][1]
+        out.append({'kernel': 'k_conv<KC=4, FE=false> (hg_conv2d_fwd) at %d->%d ch, %dx%d, batch %d' % (*key, key[2], B), 'bound': 'mfma',
+                    'achieved': fl / tf / 1e12, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / tf / 1e12 / FP32_PEAK_TFLOPS,
+                    'launch_ms': tf * 1e3})
+    K, N, S = 16 * cap, 8 * cap, size // 4
+    with torch.no_grad():
+        x = torch.randn(B, K, S, S, device=dev)
+        st = 0.3 * torch.randn(B, K, device=dev)
+        w = torch.randn(N, K, 3, 3, device=dev) / (K * 9) ** 0.5
+        nzt = torch.rand(B, size, size, device=dev)
+        wn, bn = torch.randn(N, device=dev), torch.randn(N, device=dev)
+        fn = lambda: ops.modconv_stage(x, st, w, nzt, wn, bn, demod=True, upsample=False, act=True)
+        fn(); fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(6):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / 6 * 1e-3
+    fl = 2.0 * B * S * S * K * N * 9
+    out.append({'kernel': 'k_conv<FE=true> (hg_modconv2d_fwd: modulate + conv + demodulate + noise + LeakyReLU, incl. its '
+                          'demodulation-coefficient launches) at %d->%d ch, %dx%d, batch %d' % (K, N, S, S, B), 'bound': 'mfma',
+                'achieved': fl / t / 1e12, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / t / 1e12 / FP32_PEAK_TFLOPS,
+                'launch_ms': t * 1e3})
+    return out
+
+
 def oracle_train_step(args, n, device):
     """The reference's op chain for one train step (oracle/: functional restatement of its networks + histogram block,
     stock aten ops) on `device`, for n images -- D phase: G fwd (no grad), D on fake and real, backward; G phase: G fwd,
@@ -692,6 +732,10 @@ def main():
                                          'wgrad_tflops': tot[0] / tot[3] / 1e12,
                                          'fwd_ms': tot[1] * 1e3, 'dgrad_ms': tot[2] * 1e3, 'wgrad_ms': tot[3] * 1e3},
                 'hist': hist_roof}
+        try:
+            roof['leading_kernels'] = leading_kernel_lines(dev, args.batch, ct, args.size, args.capacity)
+        except Exception as e:
+            roof['leading_kernels'] = {'error': f'{type(e).__name__}: {str(e)[:160]}'}
     else:
         roof = hist_roof
 
