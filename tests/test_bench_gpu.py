@@ -45,7 +45,9 @@ def test_bench_hist_line_has_the_contract_fields(gpu_device):
         assert k in out, k
     assert out['roofline']['bound'] == 'mfma' and 0 < out['roofline']['frac'] < 1
     assert out['cpu_baseline']['kind'] == 'port' and out['cpu_baseline']['cpu']
-    assert out['roofline']['thresholding']['bound'] == 'hbm'
+    thr = out['roofline']['thresholding']
+    assert thr['bound'] == 'hbm' and thr['north_star_hbm_target'] == 0.6
+    assert thr['north_star_hbm_target_met'] == (thr['frac'] >= 0.6)      # reported honestly, whatever it is
 
 
 def test_bench_train_stdout_is_one_json_line_under_graph_replay(gpu_device):
