@@ -156,6 +156,27 @@ def _load():
     lib.hg_grouped_linear_bwd_input.argtypes = [GL, i32, ctypes.POINTER(vp), i32, i32, i32, vp, sz, vp]
     lib.hg_grouped_linear_bwd_params.restype = ctypes.c_int
     lib.hg_grouped_linear_bwd_params.argtypes = [GL, i32, i32, i32, vp]
+    # include/hg_wino.h
+    lib.hg_wino_supported.restype = ctypes.c_int
+    lib.hg_wino_supported.argtypes = [i32, i32, i32, i32, i32]
+    lib.hg_wino_packed_elems.restype = sz
+    lib.hg_wino_packed_elems.argtypes = [i32, i32, i32]
+    lib.hg_wino_pack_weights.restype = ctypes.c_int
+    lib.hg_wino_pack_weights.argtypes = [vp, vp, i32, i32, i32, vp]
+    lib.hg_wino_pack_blocks.restype = ctypes.c_int32
+    lib.hg_wino_pack_blocks.argtypes = [i32, i32, i32, i32]
+    lib.hg_wino_pack_weights_multi.restype = ctypes.c_int
+    lib.hg_wino_pack_weights_multi.argtypes = [vp, i32, i32, vp]
+    lib.hg_wino_workspace_bytes.restype = sz
+    lib.hg_wino_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    lib.hg_wino_conv2d.restype = ctypes.c_int
+    lib.hg_wino_conv2d.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, f32, vp, i32, i32, i32, i32, i32, vp, sz, vp]
+    lib.hg_wino_wgrad_supported.restype = ctypes.c_int
+    lib.hg_wino_wgrad_supported.argtypes = [i32, i32, i32, i32, i32]
+    lib.hg_wino_wgrad_workspace_bytes.restype = sz
+    lib.hg_wino_wgrad_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    lib.hg_wino_wgrad.restype = ctypes.c_int
+    lib.hg_wino_wgrad.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]
     # include/hg_augment.h
     lib.hg_augment_spatial.restype = ctypes.c_int
     lib.hg_augment_spatial.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp]
@@ -170,7 +191,7 @@ def _load():
 
 lib = _load()
 
-# every symbol include/hg_hist.h, hg_nets.h, hg_conv.h, hg_recolor.h, hg_augment.h and hg_linear.h declare
+# every symbol include/hg_hist.h, hg_nets.h, hg_conv.h, hg_recolor.h, hg_augment.h, hg_linear.h and hg_wino.h declare
 EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg_rgbuv_hist_uses_proj_cache', 'hg_rgbuv_hist_fwd',
            'hg_rgbuv_hist_bwd', 'hg_hellinger_workspace_bytes', 'hg_hellinger_fwd_bwd', 'hg_selftest_fastlog',
            'hg_modulate_fwd', 'hg_modulate_bwd', 'hg_demod_noise_lrelu_fwd', 'hg_demod_noise_lrelu_bwd',
@@ -181,7 +202,9 @@ EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg
            'hg_instnorm_workspace_bytes', 'hg_instnorm_lrelu_fwd', 'hg_instnorm_lrelu_bwd', 'hg_stencil3',
            'hg_depthwise_valid', 'hg_augment_spatial', 'hg_augment_workspace_bytes', 'hg_sample_mean',
            'hg_augment_color', 'hg_grouped_linear_fwd', 'hg_grouped_linear_bwd_input_workspace_bytes',
-           'hg_grouped_linear_bwd_input', 'hg_grouped_linear_bwd_params')
+           'hg_grouped_linear_bwd_input', 'hg_grouped_linear_bwd_params',
+           'hg_wino_supported', 'hg_wino_packed_elems', 'hg_wino_pack_weights', 'hg_wino_pack_blocks', 'hg_wino_pack_weights_multi', 'hg_wino_workspace_bytes', 'hg_wino_conv2d',
+           'hg_wino_wgrad_supported', 'hg_wino_wgrad_workspace_bytes', 'hg_wino_wgrad')
 
 
 class HgError(RuntimeError):

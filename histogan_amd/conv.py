@@ -32,6 +32,88 @@ def _use_b6(K, N, H, W, B, k, stride):
     return PRECISION in ('b6', 'b9') and k == 3 and stride == 1 and K >= 16 and B * H * W >= B6_MIN_PIX
 
 
+# Winograd F(2x2, 3x3) for the 3x3 stride-1 output / data-gradient launches (include/hg_wino.h): the packed operand of a
+# weight carries its transformed twin as the attribute `.wino` (registered weights: written by the batched pack; others:
+# packed on first use from `.wino_src`); a launch takes it when hg_wino_supported says the shape is served and faster.
+WINO = os.environ.get('HG_WINO', '1') != '0'
+_wino_ok = {}
+
+
+def wino_supported(B, K, N, H, W):
+    key = (B, K, N, H, W)
+    r = _wino_ok.get(key)
+    if r is None:
+        r = _wino_ok[key] = bool(WINO and lib.hg_wino_supported(B, K, N, H, W))
+    return r
+
+
+_wino_wg_ok = {}
+WINO_WGRAD = os.environ.get('HG_WINO_WGRAD', '1') != '0'
+
+
+def wino_wgrad_supported(B, K, N, H, W):
+    key = (B, K, N, H, W)
+    r = _wino_wg_ok.get(key)
+    if r is None:
+        r = _wino_wg_ok[key] = bool(WINO and WINO_WGRAD and lib.hg_wino_wgrad_supported(B, K, N, H, W))
+    return r
+
+
+def _wino_pack(w, mode):
+    Co, Ci = w.shape[:2]
+    n = lib.hg_wino_packed_elems(Co, Ci, mode)
+    if not n:
+        return False
+    with on_device(w.device):
+        u = torch.empty(n, dtype=torch.float32, device=w.device)
+        check(lib.hg_wino_pack_weights(w.data_ptr(), u.data_ptr(), Co, Ci, mode, _st(w)), 'hg_wino_pack_weights')
+    return u
+
+
+def _wino_u(wt, mode, B, K, N, H, W):
+    """The Winograd operand for this launch, or None (direct kernel)."""
+    if not wino_supported(B, K, N, H, W):
+        return None
+    u = getattr(wt, 'wino', None)
+    if u is None:
+        src = getattr(wt, 'wino_src', None)
+        if src is None:
+            return None
+        u = wt.wino = _wino_pack(src, mode)
+    return None if u is False else u
+
+
+def wino_conv(x, u, N, iscale=None, oscale=None, bias=None, noise_w=None, noise_img=None, noise_S=0, slope=0.0, addend=None):
+    """hg_wino_conv2d: the fused epilogue of hg_modconv2d_fwd / hg_conv2d_fwd_add on the Winograd form."""
+    B, K, H, W = x.shape
+    with on_device(x.device):
+        out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
+        nb = lib.hg_wino_workspace_bytes(B, K, N, H, W)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
+        check(lib.hg_wino_conv2d(x.data_ptr(), u.data_ptr(), out.data_ptr(), _ptr(iscale), _ptr(oscale), _ptr(bias),
+                                 _ptr(noise_w), _ptr(noise_img), noise_S, float(slope), _ptr(addend), B, K, N, H, W,
+                                 _ptr(ws), nb, _st(x)), 'hg_wino_conv2d')
+    return out
+
+
+def modconv_fwd_packed(x, wt, N, ksize, iscale=None, oscale=None, bias=None, noise_w=None, noise_img=None, noise_S=0,
+                       slope=0.0):
+    """hg_modconv2d_fwd (stride 1): lrelu(oscale * conv(iscale * x) + bias + noise_w * noise_img) in one launch."""
+    B, K, H, W = x.shape
+    if ksize == 3 and (noise_img is None or noise_S % 2 == 0):
+        u = _wino_u(wt, PACK_FWD, B, K, N, H, W)
+        if u is not None:
+            return wino_conv(x, u, N, iscale, oscale, bias, noise_w, noise_img, noise_S, slope)
+    with on_device(x.device):
+        out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
+        nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, 1, 0)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
+        check(lib.hg_modconv2d_fwd(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(iscale), _ptr(oscale), _ptr(bias),
+                                   _ptr(noise_w), _ptr(noise_img), noise_S, float(slope), B, K, N, H, W, ksize, _ptr(ws), nb,
+                                   _st(x)), 'hg_modconv2d_fwd')
+    return out
+
+
 @contextlib.contextmanager
 def input_grads_only():
     """Inside this context the backward of conv2d does not compute weight / bias gradients (they come back as
@@ -194,6 +276,11 @@ class _PackItem(ctypes.Structure):       # include/hg_conv.h: hg_pack_item
                 ('wsq', ctypes.c_void_p)]
 
 
+class _WinoItem(ctypes.Structure):       # include/hg_wino.h: hg_wino_pack_item
+    _fields_ = [('w', ctypes.c_void_p), ('u_fwd', ctypes.c_void_p), ('u_dgrad', ctypes.c_void_p),
+                ('Co', ctypes.c_int32), ('Ci', ctypes.c_int32), ('block_begin', ctypes.c_int32), ('reserved', ctypes.c_int32)]
+
+
 def build_pack_plans(device):
     """Build the batched-pack plans of every registered flat buffer now (allocations + one small host-to-device copy each),
     e.g. before a hipGraph capture, inside which a plan cannot be built."""
@@ -219,7 +306,8 @@ def _pack_owner(owner, device, launch=True):
             if torch.cuda.is_current_stream_capturing():
                 return False          # (the table upload is not capturable: per-weight launches for this capture)
             items = (_PackItem * len(live))()
-            bufs, blocks = {}, 0
+            witems = []
+            bufs, blocks, wblocks = {}, 0, 0
             for i, (key, p) in enumerate(live):
                 Co, Ci, k, _ = p.shape
                 wf = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_FWD), dtype=torch.float32, device=device)
@@ -229,13 +317,31 @@ def _pack_owner(owner, device, launch=True):
                 bufs[key] = (wf, wd, wq)
                 items[i] = _PackItem(p.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, blocks, wq.data_ptr())
                 blocks += lib.hg_conv_pack_blocks(Co, Ci)
+                wf.wino = wd.wino = False
+                if WINO and k == 3:        # the Winograd operands of the 3x3 weights (include/hg_wino.h), one more launch
+                    nf, nd = lib.hg_wino_packed_elems(Co, Ci, PACK_FWD), lib.hg_wino_packed_elems(Co, Ci, PACK_DGRAD)
+                    if nf:
+                        wf.wino = torch.empty(nf, dtype=torch.float32, device=device)
+                    if nd:
+                        wd.wino = torch.empty(nd, dtype=torch.float32, device=device)
+                    if nf or nd:
+                        witems.append(_WinoItem(p.data_ptr(), wf.wino.data_ptr() if nf else None,
+                                                wd.wino.data_ptr() if nd else None, Co, Ci, wblocks, 0))
+                        wblocks += lib.hg_wino_pack_blocks(Co, Ci, int(bool(nf)), int(bool(nd)))
             raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).clone()
-            plan = _multi[owner] = dict(sig=sig, bufs=bufs, table=raw.to(device), n=len(live), blocks=blocks)
+            plan = _multi[owner] = dict(sig=sig, bufs=bufs, table=raw.to(device), n=len(live), blocks=blocks, wn=len(witems),
+                                        wblocks=wblocks, wtable=None)
+            if witems:
+                arr = (_WinoItem * len(witems))(*witems)
+                plan['wtable'] = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(device)
         if not launch:
             return True
         _await_pack(owner, device)         # an asynchronous pack of the same buffers still in flight goes first
         check(lib.hg_conv_pack_weights_multi(plan['table'].data_ptr(), plan['n'], plan['blocks'], raw_stream(device)),
               'hg_conv_pack_weights_multi')
+        if plan['wtable'] is not None:
+            check(lib.hg_wino_pack_weights_multi(plan['wtable'].data_ptr(), plan['wn'], plan['wblocks'], raw_stream(device)),
+                  'hg_wino_pack_weights_multi')
         _pack_events.pop(owner, None)      # (prepack_async records the event of THIS launch right after)
     for key, p in live:
         st = _stamp(p, owner)
@@ -321,6 +427,8 @@ def _pack_both(w):
         wd = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_DGRAD), dtype=torch.float32, device=w.device)
         check(lib.hg_conv_pack_weights_both(w.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, _st(w)),
               'hg_conv_pack_weights_both')
+    if k == 3:
+        wf.wino_src = wd.wino_src = w      # Winograd operands: packed by the first launch that takes them (_wino_u)
     return {PACK_FWD: wf, PACK_DGRAD: wd}
 
 
@@ -332,12 +440,18 @@ def _pack_weights(w, mode):
     with on_device(w.device):
         wt = torch.empty(n, dtype=torch.float32, device=w.device)
         check(lib.hg_conv_pack_weights(w.data_ptr(), wt.data_ptr(), Co, Ci, k, mode, _st(w)), 'hg_conv_pack_weights')
+    if k == 3:
+        wt.wino_src = w
     return wt
 
 
 def conv_fwd_packed(x, wt, N, ksize, stride=1, iscale=None, oscale=None, bias=None):
     """out[b,n] = oscale[b,n] * sum_k conv(iscale[b,k] * x[b,k], Wt[.,k,n]) + bias[n]   (x: (B,K,H,W) contiguous)."""
     B, K, H, W = x.shape
+    if ksize == 3 and stride == 1:
+        u = _wino_u(wt, PACK_FWD, B, K, N, H, W)
+        if u is not None:
+            return wino_conv(x, u, N, iscale, oscale, bias)
     with on_device(x.device):
         out = torch.empty((B, N, _out_size(H, stride), _out_size(W, stride)), dtype=torch.float32, device=x.device)
         nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, stride, 0)
@@ -350,6 +464,10 @@ def conv_fwd_packed(x, wt, N, ksize, stride=1, iscale=None, oscale=None, bias=No
 def conv_fwd_add_packed(x, wt, N, ksize, addend, bias=None, stride=1):
     """out = (conv(x, Wt) + bias[n]) + addend   (addend (B,N,Ho,Wo) contiguous: hg_conv2d_fwd_add)."""
     B, K, H, W = x.shape
+    if ksize == 3 and stride == 1 and tuple(addend.shape) == (B, N, H, W):
+        u = _wino_u(wt, PACK_FWD, B, K, N, H, W)
+        if u is not None:
+            return wino_conv(x, u, N, bias=bias, addend=addend)
     with on_device(x.device):
         out = torch.empty((B, N, _out_size(H, stride), _out_size(W, stride)), dtype=torch.float32, device=x.device)
         if addend.shape != out.shape:
@@ -378,6 +496,10 @@ def lrelu_bwd_channel_sum(g, out, slope, want_sum=True):
 def conv_dgrad_packed(g, wt, N, H, W, ksize, stride=1, iscale=None, oscale=None):
     """Data gradient: g (B,K,Ho,Wo) -> (B,N,H,W); wt packed with PACK_DGRAD."""
     B, K = g.shape[:2]
+    if ksize == 3 and stride == 1:
+        u = _wino_u(wt, PACK_DGRAD, B, K, N, H, W)
+        if u is not None:
+            return wino_conv(g, u, N, iscale, oscale)
     with on_device(g.device):
         gin = torch.empty((B, N, H, W), dtype=torch.float32, device=g.device)
         nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, stride, 1)
@@ -392,6 +514,14 @@ def conv_wgrad(x, gout, ksize, stride=1, iscale=None, gscale=None, out=None):
     out: optional contiguous (N,K,k,k) tensor to write (e.g. the weight's slice of a flat gradient buffer)."""
     B, K, H, W = x.shape
     N = gout.shape[1]
+    if ksize == 3 and stride == 1 and iscale is None and gscale is None and wino_wgrad_supported(B, K, N, H, W):
+        with on_device(x.device):     # Winograd form (include/hg_wino.h): 16 instead of 36 multiplications per tile and (n, k)
+            nbytes = lib.hg_wino_wgrad_workspace_bytes(B, K, N, H, W)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            gw = out if out is not None else torch.empty((N, K, 3, 3), dtype=torch.float32, device=x.device)
+            check(lib.hg_wino_wgrad(x.data_ptr(), gout.data_ptr(), gw.data_ptr(), B, K, N, H, W, ws.data_ptr(), nbytes, _st(x)),
+                  'hg_wino_wgrad')
+        return gw
     with on_device(x.device):
         nbytes = lib.hg_conv2d_wgrad_workspace_bytes(B, K, N, H, W, ksize, stride)
         ws = torch.empty(max(nbytes, 4), dtype=torch.uint8, device=x.device)
@@ -633,15 +763,9 @@ class _ConvLrelu(torch.autograd.Function):
         N, k = w.shape[0], w.shape[2]
         wt = pack_weights(wc, PACK_FWD)
         bc = None if bias is None else _f32c(bias)
-        with on_device(x.device):
-            out = torch.empty((B, N, _out_size(H, stride), _out_size(W, stride)), dtype=torch.float32, device=x.device)
-            if stride == 1:
-                nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, k, 1, 0)
-                ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
-                check(lib.hg_modconv2d_fwd(xc.data_ptr(), wt.data_ptr(), out.data_ptr(), None, None, _ptr(bc), None, None,
-                                           0, float(slope), B, K, N, H, W, k, _ptr(ws), nb, _st(x)), 'hg_modconv2d_fwd')
-            else:
-                raise ValueError('conv2d_lrelu: stride 1 only')
+        if stride != 1:
+            raise ValueError('conv2d_lrelu: stride 1 only')
+        out = modconv_fwd_packed(xc, wt, N, k, bias=bc, slope=slope)
         ctx.save_for_backward(x, w, out)
         ctx.stride, ctx.has_bias, ctx.slope = stride, bias is not None, float(slope)
         return out

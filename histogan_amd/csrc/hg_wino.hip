@@ -1,0 +1,922 @@
+// hg_wino.hip -- Winograd F(2x2, 3x3) convolutions on the fp32 MFMA (gfx950): include/hg_wino.h.
+//
+// The 3x3 stride-1 convolutions of the generator (Conv2DMod, histoGAN/histoGAN.py:431-439) and of the discriminator
+// blocks (:510-515), forward and data gradient, are 60 % of a train step on the direct implicit GEMM (hg_conv.hip), which
+// already runs at 0.85-0.9 of the fp32-MFMA peak on its best tiles: the only thing left to remove is multiplications.
+//
+//   Y = A^T [ U . V ] A,   U = G g G^T (4x4 per (n, k), packed once per optimizer step),  V = B^T d B (4x4 per input tile)
+//
+// One workgroup (8 waves) owns NB output channels x TB tiles (2x2 outputs each) x all 16 transform positions; wave w owns
+// positions xi = 2w, 2w+1, i.e. two independent (NB x K) x (K x TB) GEMMs on v_mfma_f32_32x32x2_f32:
+//   * A operand (U): every position's weights are used by exactly ONE wave, so they never pass through LDS -- the packing
+//     kernel lays them out in lane order and a wave fetches its operands of a K chunk with two 16-byte loads per lane.
+//   * B operand (V): each thread loads ONE 4x4 input patch (a (channel, tile) pair of the chunk) straight from global memory
+//     with unconditional buffer loads (offset 0xFFFFFFFF = zero padding, no predicates), transforms it in registers (32
+//     additions) and writes its 16 values into the position-major LDS buffer the waves read their B operands from.
+//   * double-buffered V, ONE barrier per K chunk; loads of chunk c+2 are in flight while chunk c is multiplied.
+//   * epilogue: the 16 position sums of an output tile live in 8 different waves; they meet in LDS (the dead V buffers),
+//     each thread applies A^T . A to (channel, tile) pairs, the fused epilogue of hg_modconv2d_fwd, and stores 2x2 pixels.
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include "hg_common.h"
+#include "../../include/hg_hist.h"
+#include "../../include/hg_conv.h"
+#include "../../include/hg_wino.h"
+
+namespace {
+
+constexpr unsigned kOOB = 0xFFFFFFFFu;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *base, unsigned bytes = kOOB) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+
+struct WinoArgs {
+  const float *in, *u;
+  float *out;
+  const float *iscale, *oscale, *bias, *addend, *noise_w, *noise_img;
+  int noise_S;
+  float slope;
+  int B, K, N, H, W;
+  int nblk, nch;           // channel blocks, K chunks (of the packed operand)
+  int lTW, lTH, lNI;       // log2 of the block's tile grid: tiles per row, rows, images
+  int tiles_w, tiles_h;    // 2x2 tiles of the map
+  int bt_x, bt_y;          // block tiles per map row / column
+  int ksplit;
+  float *slab;
+};
+
+// accumulator row of register r (v_mfma_f32_32x32x2_f32: D[i][j], j = lane & 31, i = row(r, lane >> 5))
+__device__ __forceinline__ int mrow(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
+
+// TC x TP MFMA tiles (32 channels x 32 tiles each) per transform position and wave; KC input channels per chunk.
+// (TC, TP, KC) = (2, 2, 8): 64 channels x 64 tiles;  (1, 4, 4): 32 channels x 128 tiles (layers with 32 output channels).
+template <int TC, int TP, int KC, bool FE>
+__global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
+  constexpr int NT = 512, NB = 32 * TC, TB = 32 * TP;
+  static_assert(KC * TB == NT, "one (channel, tile) patch per thread and chunk");
+  constexpr int NV = (KC / 2) * TC;      // A-operand floats per lane, position and chunk
+  static_assert(NV == 2 || NV % 4 == 0, "operand loads are 8 or 16 bytes");
+  constexpr int VSZ = 16 * KC * TB;      // floats of one V buffer (32 KB)
+  extern __shared__ float smem[];        // [2][16][KC][TB]; the epilogue reuses it as [16][32][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 31, lk = lane >> 5;
+  const int H = a.H, W = a.W, K = a.K, N = a.N, HW = H * W;
+
+  // block -> (channel block, block tile); the channel block varies fastest: the blocks that read the same input tiles
+  // are neighbours in dispatch order (their second read hits the Infinity Cache), and with >= 8 channel blocks every XCD
+  // only ever sees an eighth of U
+  int pt = blockIdx.x;
+  const int nb = pt % a.nblk;
+  pt /= a.nblk;
+  const int bx = pt % a.bt_x;
+  pt /= a.bt_x;
+  const int by = pt % a.bt_y;
+  const int grp = pt / a.bt_y;
+  const int n0 = nb * NB, b0 = grp << a.lNI;
+  const int TWm = (1 << a.lTW) - 1, THm = (1 << a.lTH) - 1;
+
+  // ---- this thread's patch: channel kc of the chunk, tile t of the block
+  const int t = tid % TB, kc = tid / TB;
+  unsigned vo[4][3];
+  unsigned so = kOOB;
+  {
+    const int ttx = t & TWm, tty = (t >> a.lTW) & THm, timg = t >> (a.lTW + a.lTH);
+    const int gtx = (bx << a.lTW) + ttx, gty = (by << a.lTH) + tty, b = b0 + timg;
+    const bool ok = gtx < a.tiles_w && gty < a.tiles_h && b < a.B;
+    const int x = 2 * gtx - 1, y0 = 2 * gty - 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int y = y0 + r;
+      const bool rok = ok && (unsigned)y < (unsigned)H;
+      const unsigned e = (unsigned)(((timg * K + kc) * H + y) * W + x);
+      vo[r][0] = (rok && x >= 0) ? e * 4u : kOOB;
+      vo[r][1] = rok ? (e + 1u) * 4u : kOOB;
+      vo[r][2] = (rok && x + 3 < W) ? (e + 3u) * 4u : kOOB;
+    }
+    if (FE && ok) so = (unsigned)(b * K + kc) * 4u;
+  }
+  const float *inblk = a.in + (size_t)b0 * K * HW;
+  const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u);
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(FE && a.iscale ? a.iscale : a.u);
+  const bool has_is = FE && a.iscale != nullptr;
+
+  // this wave's operand slices of U: position xi = 2 wave + x2
+  unsigned uo[2];
+#pragma unroll
+  for (int x2 = 0; x2 < 2; ++x2)
+    uo[x2] = (unsigned)((((2 * wave + x2) * a.nblk + nb) * a.nch) * (NV * 64) + lane * (NV >= 4 ? 4 : 2)) * 4u;
+
+  f32x16 acc[2][TC][TP];
+#pragma unroll
+  for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+      for (int j = 0; j < TP; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x2][i][j][r] = 0.f;
+
+  float pd[16];
+  float ps = 1.f;
+  float ua[2][2][NV];   // [register set][position][operand]
+
+  auto load_patch = [&](int c) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(inblk + (size_t)c * KC * HW);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pd[4 * r] = buf_load(rx, vo[r][0], 0);
+      const f32x2 m = buf_load2(rx, vo[r][1], 0);
+      pd[4 * r + 1] = m[0];
+      pd[4 * r + 2] = m[1];
+      pd[4 * r + 3] = buf_load(rx, vo[r][2], 0);
+    }
+    if constexpr (FE) {
+      if (has_is) ps = buf_load(rs, so, c * KC * 4);
+    }
+  };
+  auto load_u = [&](int c, auto SET) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+#pragma unroll
+    for (int x2 = 0; x2 < 2; ++x2) {
+      if constexpr (NV >= 4) {
+#pragma unroll
+        for (int q = 0; q < NV / 4; ++q) {
+          const f32x4 v = buf_load4(ru, uo[x2] + (unsigned)q * 1024u, c * NV * 64 * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ua[S][x2][4 * q + e] = v[e];
+        }
+      } else {
+        const f32x2 v = buf_load2(ru, uo[x2], c * NV * 64 * 4);
+        ua[S][x2][0] = v[0];
+        ua[S][x2][1] = v[1];
+      }
+    }
+  };
+  // V = B^T d B of the prefetched patch into buffer `buf`
+  auto transform_store = [&](int buf) __attribute__((always_inline)) {
+    float *Vb = smem + buf * VSZ + kc * TB + t;
+    float d[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) d[e] = has_is ? pd[e] * ps : pd[e];
+    float q[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      q[0 + c] = d[0 + c] - d[8 + c];
+      q[4 + c] = d[4 + c] + d[8 + c];
+      q[8 + c] = d[8 + c] - d[4 + c];
+      q[12 + c] = d[4 + c] - d[12 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Vb[(4 * r + 0) * KC * TB] = q[4 * r] - q[4 * r + 2];
+      Vb[(4 * r + 1) * KC * TB] = q[4 * r + 1] + q[4 * r + 2];
+      Vb[(4 * r + 2) * KC * TB] = q[4 * r + 2] - q[4 * r + 1];
+      Vb[(4 * r + 3) * KC * TB] = q[4 * r + 1] - q[4 * r + 3];
+    }
+  };
+  auto mfma_chunk = [&](int buf, auto SET) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    const float *Vc = smem + buf * VSZ + lk * TB + lm;
+    // all B operands of the chunk up front (16 registers): the MFMAs then run back to back
+    float bv[2][KC / 2][TP];
+#pragma unroll
+    for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+      for (int ks = 0; ks < KC / 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < TP; ++j) bv[x2][ks][j] = Vc[((2 * wave + x2) * KC + 2 * ks) * TB + 32 * j];
+#pragma unroll
+    for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+      for (int ks = 0; ks < KC / 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+          for (int j = 0; j < TP; ++j)
+            acc[x2][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[S][x2][ks * TC + i], bv[x2][ks][j], acc[x2][i][j], 0, 0, 0);
+  };
+
+  // K chunks of this split.  Two chunks per trip (V buffer / operand register set 0, then 1), and every load of the loop
+  // body is UNCONDITIONAL (past the end the chunk index is clamped: a redundant load nobody consumes): with loads behind
+  // branches the compiler has to assume the shortest path and waits for (almost) every outstanding load before the first
+  // MFMA of a chunk -- the global latency then runs in series with the MFMAs instead of under them.
+  const int cps = (a.nch + a.ksplit - 1) / a.ksplit;
+  const int c_begin = blockIdx.z * cps;
+  const int c_end = c_begin + cps < a.nch ? c_begin + cps : a.nch;
+  const int nc = c_end - c_begin;
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
+  auto clampc = [&](int c) __attribute__((always_inline)) { return c < c_end ? c : c_end - 1; };
+
+  if (nc > 0) {
+    load_patch(c_begin);
+    load_u(c_begin, S0{});
+    transform_store(0);
+    load_patch(clampc(c_begin + 1));
+    load_u(clampc(c_begin + 1), S1{});
+    __syncthreads();
+    for (int c = c_begin; c + 1 < c_end; c += 2) {
+      // (sched_barrier: the scheduler otherwise hoists the first additions of the NEXT transform up to right behind the
+      // loads they consume -- an s_waitcnt for just-issued loads in the middle of the loop)
+      mfma_chunk(0, S0{});
+      __builtin_amdgcn_sched_barrier(0);   // the transform BEHIND the MFMAs: its patch was requested one phase ago, no sooner
+      transform_store(1);
+      load_patch(clampc(c + 2));
+      load_u(clampc(c + 2), S0{});
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_chunk(1, S1{});
+      __builtin_amdgcn_sched_barrier(0);
+      transform_store(0);
+      load_patch(clampc(c + 3));
+      load_u(clampc(c + 3), S1{});
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nc & 1) mfma_chunk(0, S0{});
+  }
+
+  // ---- epilogue: one (channel tile, tile tile) pair at a time through LDS
+  const bool fin = a.ksplit == 1;
+  float *ob = fin ? a.out : a.slab + (size_t)blockIdx.z * a.B * N * HW;
+  const int erow = tid >> 5, ecol = tid & 31;
+#pragma unroll
+  for (int i = 0; i < TC; ++i) {
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+      __syncthreads();   // (first pass: every wave is done with the V buffers this staging area aliases)
+#pragma unroll
+      for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) smem[((2 * wave + x2) * 32 + mrow(r, lk)) * 32 + lm] = acc[x2][i][j][r];
+      __syncthreads();
+      const int tl = 32 * j + ecol;
+      const int ttx = tl & TWm, tty = (tl >> a.lTW) & THm, timg = tl >> (a.lTW + a.lTH);
+      const int gtx = (bx << a.lTW) + ttx, gty = (by << a.lTH) + tty, b = b0 + timg;
+      const bool ok = gtx < a.tiles_w && gty < a.tiles_h && b < a.B;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int row = erow + 16 * h;
+        const int n = n0 + 32 * i + row;
+        float m[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m[e] = smem[(e * 32 + row) * 32 + ecol];
+        if (!ok || n >= N) continue;
+        float s0[4], s1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          s0[c] = m[c] + m[4 + c] + m[8 + c];
+          s1[c] = m[4 + c] - m[8 + c] - m[12 + c];
+        }
+        float y[2][2];
+        y[0][0] = s0[0] + s0[1] + s0[2];
+        y[0][1] = s0[1] - s0[2] - s0[3];
+        y[1][0] = s1[0] + s1[1] + s1[2];
+        y[1][1] = s1[1] - s1[2] - s1[3];
+        const size_t o = (((size_t)b * N + n) * H + 2 * gty) * W + 2 * gtx;
+        if (fin) {
+          const float bias = a.bias ? a.bias[n] : 0.f;
+          const float osc = a.oscale ? a.oscale[b * N + n] : 1.f;
+          const float nw = a.noise_img ? a.noise_w[n] : 0.f;
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            f32x2 nz = {0.f, 0.f};
+            if (a.noise_img)
+              nz = *reinterpret_cast<const f32x2 *>(a.noise_img + ((size_t)b * a.noise_S + 2 * gty + p) * a.noise_S + 2 * gtx);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              float v = fmaf(y[p][q], osc, fmaf(nw, nz[q], bias));
+              if (a.addend) v += a.addend[o + p * W + q];
+              if (a.slope > 0.f) v = v > 0.f ? v : a.slope * v;
+              y[p][q] = v;
+            }
+          }
+        }
+        *reinterpret_cast<f32x2 *>(ob + o) = f32x2{y[0][0], y[0][1]};
+        *reinterpret_cast<f32x2 *>(ob + o + W) = f32x2{y[1][0], y[1][1]};
+      }
+    }
+  }
+}
+
+// out = epilogue(sum_z slab[z]) in fixed order (as k_splitk_reduce of hg_conv.hip)
+__global__ __launch_bounds__(256) void k_wino_reduce(const float *__restrict__ slab, float *__restrict__ out,
+                                                     const float *__restrict__ oscale, const float *__restrict__ bias,
+                                                     const float *__restrict__ noise_w, const float *__restrict__ noise_img,
+                                                     const float *__restrict__ addend, int noise_S, float slope,
+                                                     long long total4, int HW, int W, int N, int ksplit) {
+  const size_t total = (size_t)total4 * 4;
+  for (long long i4 = (long long)blockIdx.x * 256 + threadIdx.x; i4 < total4; i4 += (long long)gridDim.x * 256) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < ksplit; ++z) v += *reinterpret_cast<const f32x4 *>(slab + (size_t)z * total + (size_t)i4 * 4);
+    const long long i = i4 * 4;
+    const long long bn = i / HW;
+    const int n = (int)(bn % N);
+    const float bs = bias ? bias[n] : 0.f, osc = oscale ? oscale[bn] : 1.f, nw = noise_img ? noise_w[n] : 0.f;
+    f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+    if (noise_img) {
+      const int p = (int)(i - bn * HW), y = p / W, x = p - y * W;   // W % 4 == 0 is not guaranteed: element-wise
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int xe = x + e, ye = y + xe / W;
+        nz[e] = noise_img[((size_t)(bn / N) * noise_S + ye) * noise_S + xe % W];
+      }
+    }
+    f32x4 ad = {0.f, 0.f, 0.f, 0.f};
+    if (addend) ad = *reinterpret_cast<const f32x4 *>(addend + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float r = fmaf(v[e], osc, fmaf(nw, nz[e], bs)) + ad[e];
+      if (slope > 0.f) r = r > 0.f ? r : slope * r;
+      v[e] = r;
+    }
+    *reinterpret_cast<f32x4 *>(out + i) = v;
+  }
+}
+
+// U = G g G^T of every (n, k) pair in the lane order k_wino<TC, *, KC> loads: one thread per operand slot of chunk `ch`,
+// channel block `nb`, sixteen coalesced stores.  mode DGRAD: k = Co, n = Ci, taps flipped (== positions 0 <-> 3 swapped
+// in both directions, since G J = P G for the 3x3 flip J and the row swap P).
+template <int TC, int KC>
+__device__ __forceinline__ void wino_pack_slot(const float *__restrict__ w, float *__restrict__ u, int Co, int Ci, int nblk,
+                                               int nch, int mode, int ch, int nb, int tid /* < NV * 64 */) {
+  constexpr int NV = (KC / 2) * TC, NB = 32 * TC;
+  int e, lane;
+  if constexpr (NV >= 4) {
+    e = (tid >> 8) * 4 + (tid & 3);
+    lane = (tid >> 2) & 63;
+  } else {
+    e = tid & 1;
+    lane = tid >> 1;
+  }
+  const int ks = e / TC, i = e % TC, lm = lane & 31, lk = lane >> 5;
+  const int k = ch * KC + 2 * ks + lk, n = nb * NB + 32 * i + lm;
+  const int K = mode == HG_CONV_PACK_FWD ? Ci : Co, N = mode == HG_CONV_PACK_FWD ? Co : Ci;
+  float g[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) g[q] = 0.f;
+  if (k < K && n < N) {
+    const float *p = w + (mode == HG_CONV_PACK_FWD ? ((size_t)n * Ci + k) : ((size_t)k * Ci + n)) * 9;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) g[q] = p[q];
+  }
+  // rows: G g (4 x 3), then columns: (G g) G^T (4 x 4)
+  float gg[4][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    gg[0][c] = g[c];
+    gg[1][c] = 0.5f * (g[c] + g[3 + c] + g[6 + c]);
+    gg[2][c] = 0.5f * (g[c] - g[3 + c] + g[6 + c]);
+    gg[3][c] = g[6 + c];
+  }
+  float uu[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    uu[r][0] = gg[r][0];
+    uu[r][1] = 0.5f * (gg[r][0] + gg[r][1] + gg[r][2]);
+    uu[r][2] = 0.5f * (gg[r][0] - gg[r][1] + gg[r][2]);
+    uu[r][3] = gg[r][2];
+  }
+  const size_t xstride = (size_t)nblk * nch * (NV * 64);
+  float *dst = u + ((size_t)nb * nch + ch) * (NV * 64) + tid;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int rr = mode == HG_CONV_PACK_FWD ? r : (r == 0 ? 3 : (r == 3 ? 0 : r));
+      const int cc = mode == HG_CONV_PACK_FWD ? c : (c == 0 ? 3 : (c == 3 ? 0 : c));
+      dst[(size_t)(4 * r + c) * xstride] = uu[rr][cc];
+    }
+}
+
+// geometry of the packed operand of one (weight, mode): variant (0: 64-channel blocks, 8-channel chunks; 1: 32 / 4),
+// channel blocks, chunks, and the 512-thread pack blocks that write it (variant 1: four chunks per block)
+struct PackGeom {
+  int variant, nblk, nch, blocks;
+};
+__host__ __device__ inline PackGeom pack_geom(int Co, int Ci, int mode, int force_variant) {
+  const int K = mode == HG_CONV_PACK_FWD ? Ci : Co, N = mode == HG_CONV_PACK_FWD ? Co : Ci;
+  PackGeom g;
+  g.variant = force_variant >= 0 ? force_variant : (N <= 32 ? 1 : 0);
+  const int NB = g.variant ? 32 : 64, KC = g.variant ? 4 : 8;
+  g.nblk = (N + NB - 1) / NB;
+  g.nch = K / KC;
+  g.blocks = (K % KC) ? 0 : (g.variant ? ((g.nch + 3) / 4) * g.nblk : g.nch * g.nblk);
+  return g;
+}
+// pack block `local` (512 threads) of one (weight, mode)
+__device__ __forceinline__ void wino_pack_block(const float *w, float *u, int Co, int Ci, int mode, const PackGeom &g, int local) {
+  if (g.variant == 0) {
+    wino_pack_slot<2, 8>(w, u, Co, Ci, g.nblk, g.nch, mode, local % g.nch, local / g.nch, threadIdx.x);
+  } else {
+    const int cg = (g.nch + 3) / 4;
+    const int ch = (local % cg) * 4 + (threadIdx.x >> 7);
+    if (ch < g.nch) wino_pack_slot<1, 4>(w, u, Co, Ci, g.nblk, g.nch, mode, ch, local / cg, threadIdx.x & 127);
+  }
+}
+__global__ __launch_bounds__(512) void k_wino_pack(const float *__restrict__ w, float *__restrict__ u, int Co, int Ci, int mode,
+                                                   int force_variant) {
+  const PackGeom g = pack_geom(Co, Ci, mode, force_variant);
+  wino_pack_block(w, u, Co, Ci, mode, g, blockIdx.x);
+}
+// every 3x3 weight of a model, both modes, in ONE launch (the table of hg_wino_pack_weights_multi)
+__global__ __launch_bounds__(512) void k_wino_pack_multi(const hg_wino_pack_item *__restrict__ items, int n_items,
+                                                         int force_variant) {
+  int it = 0;
+  while (it + 1 < n_items && (int)blockIdx.x >= items[it + 1].block_begin) ++it;   // wave-uniform scan
+  const hg_wino_pack_item im = items[it];
+  int local = (int)blockIdx.x - im.block_begin;
+  const PackGeom gf = pack_geom(im.Co, im.Ci, HG_CONV_PACK_FWD, force_variant);
+  const int bf = im.u_fwd ? gf.blocks : 0;
+  if (local < bf) {
+    wino_pack_block(im.w, im.u_fwd, im.Co, im.Ci, HG_CONV_PACK_FWD, gf, local);
+    return;
+  }
+  local -= bf;
+  const PackGeom gd = pack_geom(im.Co, im.Ci, HG_CONV_PACK_DGRAD, force_variant);
+  if (im.u_dgrad && local < gd.blocks) wino_pack_block(im.w, im.u_dgrad, im.Co, im.Ci, HG_CONV_PACK_DGRAD, gd, local);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient:  dW = G^T [ sum_tiles (A dY A^T) . (B^T d B) ] G
+// Per transform position the sum over tiles is an (N x tiles) x (tiles x K) GEMM whose reduction index is the tile.  One
+// workgroup owns 64 n x 64 k x 16 positions (wave w: positions 2w, 2w+1, 2x2 MFMA tiles each) and walks over chunks of 8
+// tiles: each thread transforms ONE input patch (channel k, tile t) into V and ONE 2x2 output-gradient tile (channel n,
+// tile t) into A dY A^T, both position-major in LDS ([position][tile][channel], pitch 68: conflict-free stores with lanes
+// along the tiles, conflict-free operand reads with lanes along the channels).  The chunks of a block are strided over
+// the splits; the partial sums go to slabs [split][position][n][k] and k_wino_wgrad_reduce sums them in fixed order and
+// applies G^T . G.
+struct WinoWgArgs {
+  const float *in, *gout;
+  float *slab;
+  int B, K, N, H, W;
+  int ktiles, splits, nchunks;
+  int lPW, lPH, lPI;       // log2 of the chunk pattern: tiles per row, rows, images (PW * PH * PI == 8)
+  int lcg, lrg;            // log2 of the column / row groups of a map (tiles_w >> lPW, tiles_h >> lPH)
+  int Np, Kp;              // slab extents (multiples of 64)
+};
+
+constexpr int WG_P = 68;                   // LDS row pitch (floats) of a [position][tile] row of 64 channels
+constexpr int WG_OP = 16 * 8 * WG_P;       // floats of one operand buffer
+
+__global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
+  extern __shared__ float smem[];          // [2 buffers][dM, V][16][8][WG_P]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 31, lk = lane >> 5;
+  const int H = a.H, W = a.W, K = a.K, N = a.N, HW = H * W;
+  const int k0 = (blockIdx.x % a.ktiles) * 64, n0 = (blockIdx.x / a.ktiles) * 64;
+
+  // ---- transform role: tile t of the chunk pattern, channel ch of the block's 64 (input channel k0 + ch / gradient
+  //      channel n0 + ch)
+  const int t = lane & 7, ch = wave * 8 + (lane >> 3);
+  const int PWm = (1 << a.lPW) - 1, PHm = (1 << a.lPH) - 1;
+  const int dtx = t & PWm, dty = (t >> a.lPW) & PHm, dimg = t >> (a.lPW + a.lPH);
+  const int nrg = 1 << a.lrg, ncg = 1 << a.lcg;
+  const bool l_row0 = dty == 0, l_rowl = dty == PHm, l_tx0 = dtx == 0, l_txl = dtx == PWm;
+  const bool kok = k0 + ch < K, nok = n0 + ch < N;
+  // patch element (r, c) relative to the chunk origin, against a base one row and one column BEFORE the image group
+  unsigned vo[4][3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned e = (unsigned)(((dimg * K + k0 + ch) * H + 2 * dty + r) * W + 2 * dtx);
+    vo[r][0] = e * 4u;
+    vo[r][1] = (e + 1u) * 4u;
+    vo[r][2] = (e + 3u) * 4u;
+  }
+  const unsigned go = (unsigned)(((dimg * N + n0 + ch) * H + 2 * dty) * W + 2 * dtx) * 4u;
+
+  f32x16 acc[2][2][2];
+#pragma unroll
+  for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x2][i][j][r] = 0.f;
+
+  float pd[16], gd[4];
+  auto load_chunk = [&](int c) __attribute__((always_inline)) {
+    // chunk -> (image group, row group, column group): scalar
+    const int cg = c & (ncg - 1), rg = (c >> a.lcg) & (nrg - 1), ig = c >> (a.lcg + a.lrg);
+    const int b0 = ig << a.lPI;
+    const bool top = rg == 0, bot = rg == nrg - 1, left = cg == 0, right = cg == ncg - 1;
+    const bool iok = b0 + dimg < a.B;
+    const unsigned soff = (unsigned)(((rg << a.lPH) * 2) * W + (cg << a.lPW) * 2) * 4u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.in + (size_t)b0 * K * HW - (W + 1));
+    const __amdgpu_buffer_rsrc_t rg_ = make_rsrc(a.gout + (size_t)b0 * N * HW);
+    const bool ri0 = top && l_row0, ri3 = bot && l_rowl, ci0 = left && l_tx0, ci3 = right && l_txl;
+    const bool ok = iok && kok;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool rinv = !ok || (r == 0 && ri0) || (r == 3 && ri3);
+      pd[4 * r] = buf_load(rx, (rinv || ci0) ? kOOB : vo[r][0], (int)soff);
+      const f32x2 m = buf_load2(rx, rinv ? kOOB : vo[r][1], (int)soff);
+      pd[4 * r + 1] = m[0];
+      pd[4 * r + 2] = m[1];
+      pd[4 * r + 3] = buf_load(rx, (rinv || ci3) ? kOOB : vo[r][2], (int)soff);
+    }
+    const bool gok = iok && nok;
+    const f32x2 g0 = buf_load2(rg_, gok ? go : kOOB, (int)soff);
+    const f32x2 g1 = buf_load2(rg_, gok ? go + (unsigned)W * 4u : kOOB, (int)soff);
+    gd[0] = g0[0]; gd[1] = g0[1]; gd[2] = g1[0]; gd[3] = g1[1];
+  };
+  auto transform_store = [&](int buf) __attribute__((always_inline)) {
+    float *Mb = smem + buf * 2 * WG_OP + t * WG_P + ch;   // dM [position][tile][n]
+    float *Vb = Mb + WG_OP;                               // V  [position][tile][k]
+    // V = B^T d B
+    float q[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      q[0 + c] = pd[0 + c] - pd[8 + c];
+      q[4 + c] = pd[4 + c] + pd[8 + c];
+      q[8 + c] = pd[8 + c] - pd[4 + c];
+      q[12 + c] = pd[4 + c] - pd[12 + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Vb[(4 * r + 0) * 8 * WG_P] = q[4 * r] - q[4 * r + 2];
+      Vb[(4 * r + 1) * 8 * WG_P] = q[4 * r + 1] + q[4 * r + 2];
+      Vb[(4 * r + 2) * 8 * WG_P] = q[4 * r + 2] - q[4 * r + 1];
+      Vb[(4 * r + 3) * 8 * WG_P] = q[4 * r + 1] - q[4 * r + 3];
+    }
+    // dM = A dY A^T,  A = [[1, 0], [1, 1], [1, -1], [0, -1]]
+    const float r0[2] = {gd[0], gd[1]}, r1[2] = {gd[0] + gd[2], gd[1] + gd[3]}, r2[2] = {gd[0] - gd[2], gd[1] - gd[3]},
+                r3[2] = {-gd[2], -gd[3]};
+    const float *rows[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      Mb[(4 * r + 0) * 8 * WG_P] = rows[r][0];
+      Mb[(4 * r + 1) * 8 * WG_P] = rows[r][0] + rows[r][1];
+      Mb[(4 * r + 2) * 8 * WG_P] = rows[r][0] - rows[r][1];
+      Mb[(4 * r + 3) * 8 * WG_P] = -rows[r][1];
+    }
+  };
+  auto mfma_chunk = [&](int buf) __attribute__((always_inline)) {
+    const float *Mc = smem + buf * 2 * WG_OP + lk * WG_P + lm;
+    const float *Vc = Mc + WG_OP;
+#pragma unroll
+    for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        const int row = ((2 * wave + x2) * 8 + 2 * s_) * WG_P;
+        float av[2], bv[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) av[i] = Mc[row + 32 * i];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[j] = Vc[row + 32 * j];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[x2][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[x2][i][j], 0, 0, 0);
+      }
+  };
+
+  // this block's chunks: split, split + splits, ...  (two per trip; loads unconditional with a clamped index, as k_wino)
+  const int sp = blockIdx.y;
+  const int nc = sp < a.nchunks ? (a.nchunks - sp + a.splits - 1) / a.splits : 0;
+  auto chunk_of = [&](int it) __attribute__((always_inline)) { return sp + (it < nc ? it : nc - 1) * a.splits; };
+  if (nc > 0) {
+    load_chunk(chunk_of(0));
+    transform_store(0);
+    load_chunk(chunk_of(1));
+    __syncthreads();
+    for (int it = 0; it + 1 < nc; it += 2) {
+      mfma_chunk(0);
+      __builtin_amdgcn_sched_barrier(0);
+      transform_store(1);
+      load_chunk(chunk_of(it + 2));
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_chunk(1);
+      __builtin_amdgcn_sched_barrier(0);
+      transform_store(0);
+      load_chunk(chunk_of(it + 3));
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nc & 1) mfma_chunk(0);
+  }
+
+  // slab[split][position][n][k]: D[i = n][j = k], 32 consecutive lanes write 32 consecutive k
+  float *sb = a.slab + (size_t)sp * 16 * a.Np * a.Kp;
+#pragma unroll
+  for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sb[((size_t)(2 * wave + x2) * a.Np + n0 + 32 * i + mrow(r, lk)) * a.Kp + k0 + 32 * j + lm] = acc[x2][i][j][r];
+}
+
+// gw[n][k][3][3] = G^T (sum_s slab[s][.][n][k]) G.  One thread per (n, 4 consecutive k): 16-byte loads, fixed split order.
+__global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float *__restrict__ slab, float *__restrict__ gw, int N, int K,
+                                                           int Np, int Kp, int splits) {
+  const int kq = Kp / 4;
+  const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (long long)N * kq) return;
+  const int n = (int)(id / kq), k4 = (int)(id % kq) * 4;
+  const size_t pstride = (size_t)Np * Kp, sstride = 16 * pstride;
+  const float *p = slab + (size_t)n * Kp + k4;
+  f32x4 u[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) u[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s_ = 0; s_ < splits; ++s_) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) u[e] += *reinterpret_cast<const f32x4 *>(p + (size_t)s_ * sstride + e * pstride);
+  }
+  // rows: G^T u (3 x 4), G^T = [[1, .5, .5, 0], [0, .5, -.5, 0], [0, .5, .5, 1]]; then the same along the columns
+  f32x4 tq[3][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const f32x4 hs = 0.5f * (u[4 + c] + u[8 + c]), hd = 0.5f * (u[4 + c] - u[8 + c]);
+    tq[0][c] = u[c] + hs;
+    tq[1][c] = hd;
+    tq[2][c] = hs + u[12 + c];
+  }
+  f32x4 g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const f32x4 hs = 0.5f * (tq[r][1] + tq[r][2]), hd = 0.5f * (tq[r][1] - tq[r][2]);
+    g[r][0] = tq[r][0] + hs;
+    g[r][1] = hd;
+    g[r][2] = hs + tq[r][3];
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (k4 + e >= K) break;
+    float *dst = gw + ((size_t)n * K + k4 + e) * 9;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dst[3 * r + c] = g[r][c][e];
+  }
+}
+
+inline int ceil_log2(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+inline int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+// the variant serving N output channels: 0 = 64 ch x 64 tiles (KC 8), 1 = 32 ch x 128 tiles (KC 4)
+inline int force_variant() {
+  static const int force = getenv("HG_WINO_VARIANT") ? atoi(getenv("HG_WINO_VARIANT")) : -1;
+  return force;
+}
+inline int variant_of(int N) { return force_variant() >= 0 ? force_variant() : (N <= 32 ? 1 : 0); }
+struct WinoPlan {
+  int variant, NB, TB, KC, nblk, nch;
+  int lTW, lTH, lNI, tiles_w, tiles_h, bt_x, bt_y, groups;
+  int ksplit;
+  long long blocks;   // before the K split
+};
+inline bool make_plan(int B, int K, int N, int H, int W, WinoPlan &p) {
+  if (B <= 0 || K <= 0 || N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) return false;
+  p.variant = variant_of(N);
+  p.NB = p.variant ? 32 : 64;
+  p.TB = p.variant ? 128 : 64;
+  p.KC = p.variant ? 4 : 8;
+  if (K % p.KC) return false;
+  p.nblk = (N + p.NB - 1) / p.NB;
+  p.nch = K / p.KC;
+  p.tiles_w = W / 2;
+  p.tiles_h = H / 2;
+  const int lTB = ceil_log2(p.TB);
+  p.lTW = ceil_log2(p.tiles_w);
+  if (p.lTW > 4) p.lTW = 4;
+  p.lTH = ceil_log2(p.tiles_h);
+  if (p.lTH > lTB - p.lTW) p.lTH = lTB - p.lTW;
+  p.lNI = lTB - p.lTW - p.lTH;
+  p.bt_x = (p.tiles_w + (1 << p.lTW) - 1) >> p.lTW;
+  p.bt_y = (p.tiles_h + (1 << p.lTH) - 1) >> p.lTH;
+  p.groups = (B + (1 << p.lNI) - 1) >> p.lNI;
+  p.blocks = (long long)p.nblk * p.bt_x * p.bt_y * p.groups;
+  // 32-bit byte offsets: one block's images, the packed operand
+  if ((long long)(1 << p.lNI) * K * H * W >= (1LL << 30)) return false;
+  if (16LL * p.nblk * p.nch * ((p.KC / 2) * (p.NB / 32) * 64) >= (1LL << 30)) return false;
+  if ((long long)B * N * H * W >= (1LL << 31) || (long long)B * K * H * W >= (1LL << 31)) return false;
+  // K split: one block per CU; rounds of the chip in units of one chunk, + ~6 chunks of prologue / epilogue per block
+  static const int force_ks = getenv("HG_WINO_KSPLIT") ? atoi(getenv("HG_WINO_KSPLIT")) : 0;
+  const int cus = num_cus();
+  int best = 1;
+  double best_t = 1e300;
+  for (int ks = 1; ks <= 16; ++ks) {
+    if (ks > 1 && p.nch / ks < 8) break;
+    const long long rounds = (p.blocks * ks + cus - 1) / cus;
+    double t = (double)rounds * ((p.nch + ks - 1) / ks + 6);
+    if (ks > 1) t += 4.0 + 0.02 * ks * rounds;   // slab traffic + the reduce launch
+    if (t < best_t * 0.97) { best_t = t; best = ks; }
+  }
+  p.ksplit = force_ks > 0 ? (force_ks < p.nch ? force_ks : p.nch) : best;
+  return true;
+}
+
+struct WgPlan {
+  int lPW, lPH, lPI, lcg, lrg, nchunks, ktiles, ntiles, splits;
+  size_t slab_bytes;
+};
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+inline bool make_wg_plan(int B, int K, int N, int H, int W, WgPlan &p) {
+  if (B <= 0 || K <= 0 || N <= 0 || H < 2 || W < 2 || (H & 1) || (W & 1)) return false;
+  const int tw = W / 2, th = H / 2;
+  if (!is_pow2(tw) || !is_pow2(th)) return false;
+  const int ltw = ceil_log2(tw), lth = ceil_log2(th);
+  p.lPW = ltw < 3 ? ltw : 3;
+  p.lPH = lth < 3 - p.lPW ? lth : 3 - p.lPW;
+  p.lPI = 3 - p.lPW - p.lPH;
+  p.lcg = ltw - p.lPW;
+  p.lrg = lth - p.lPH;
+  const int igroups = (B + (1 << p.lPI) - 1) >> p.lPI;
+  const long long nch = (long long)igroups << (p.lcg + p.lrg);
+  if (nch > (1 << 30)) return false;
+  p.nchunks = (int)nch;
+  p.ktiles = (K + 63) / 64;
+  p.ntiles = (N + 63) / 64;
+  // 32-bit byte offsets inside one image group (+ one map of scalar offset)
+  if ((long long)((1 << p.lPI) * (K > N ? K : N) + 1) * H * W >= (1LL << 30)) return false;
+  const int tiles = p.ktiles * p.ntiles, cus = num_cus();
+  static const int force = getenv("HG_WINO_WG_SPLITS") ? atoi(getenv("HG_WINO_WG_SPLITS")) : 0;
+  int s = tiles >= cus ? 1 : (cus + tiles - 1) / tiles;
+  if (force > 0) s = force;
+  if (s > p.nchunks) s = p.nchunks;
+  if (s < 1) s = 1;
+  p.splits = s;
+  p.slab_bytes = (size_t)s * 16 * (p.ntiles * 64) * (p.ktiles * 64) * sizeof(float);
+  return true;
+}
+
+template <int TC, int TP, int KC>
+int launch_wino(const WinoArgs &a, const WinoPlan &p, bool fe, hipStream_t st) {
+  auto kern = fe ? k_wino<TC, TP, KC, true> : k_wino<TC, TP, KC, false>;
+  constexpr size_t lds = 2 * 16 * KC * 32 * TP * sizeof(float);
+  static bool attr[2] = {false, false};
+  if (!attr[fe]) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr[fe] = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks, 1, (unsigned)p.ksplit), dim3(512), lds, st, a);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hg_wino_supported(int32_t B, int32_t K, int32_t N, int32_t H, int32_t W) {
+  WinoPlan p;
+  if (!make_plan(B, K, N, H, W, p)) return 0;
+  // measured against the direct kernel at the C3 shapes (tools/wino_probe.py, profiles/r05_wino_probe.txt): the 64-channel
+  // variant wins from 32 input channels on (1.15x at 32 -> 64, 1.4-1.9x from 64 up), the 32-channel variant (twice the
+  // transform work per MFMA) only with >= 64 input channels (1.19x at 64 -> 32 @256^2; 0.94-1.09x at 32 -> 32)
+  static const int min_k0 = getenv("HG_WINO_MIN_K") ? atoi(getenv("HG_WINO_MIN_K")) : 32;
+  static const int min_k1 = getenv("HG_WINO_MIN_K1") ? atoi(getenv("HG_WINO_MIN_K1")) : 64;
+  if (K < (p.variant ? min_k1 : min_k0)) return 0;
+  return p.blocks * p.ksplit >= num_cus() / 2;
+}
+
+size_t hg_wino_packed_elems(int32_t Co, int32_t Ci, int32_t mode) {
+  if (Co <= 0 || Ci <= 0 || (mode != HG_CONV_PACK_FWD && mode != HG_CONV_PACK_DGRAD)) return 0;
+  const PackGeom g = pack_geom(Co, Ci, mode, force_variant());
+  if (!g.blocks) return 0;
+  return (size_t)16 * g.nblk * g.nch * (g.variant ? 128 : 512);
+}
+
+int hg_wino_pack_weights(const float *w, float *u, int32_t Co, int32_t Ci, int32_t mode, void *stream) {
+  if (!w || !u || !hg_wino_packed_elems(Co, Ci, mode)) return HG_EINVAL;
+  const PackGeom g = pack_geom(Co, Ci, mode, force_variant());
+  hipLaunchKernelGGL(k_wino_pack, dim3((unsigned)g.blocks), dim3(512), 0, (hipStream_t)stream, w, u, Co, Ci, mode, force_variant());
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+int32_t hg_wino_pack_blocks(int32_t Co, int32_t Ci, int32_t want_fwd, int32_t want_dgrad) {
+  if (Co <= 0 || Ci <= 0) return 0;
+  return (want_fwd ? pack_geom(Co, Ci, HG_CONV_PACK_FWD, force_variant()).blocks : 0) +
+         (want_dgrad ? pack_geom(Co, Ci, HG_CONV_PACK_DGRAD, force_variant()).blocks : 0);
+}
+
+int hg_wino_pack_weights_multi(const hg_wino_pack_item *items_dev, int32_t n_items, int32_t total_blocks, void *stream) {
+  if (!items_dev || n_items <= 0 || total_blocks <= 0) return HG_EINVAL;
+  hipLaunchKernelGGL(k_wino_pack_multi, dim3((unsigned)total_blocks), dim3(512), 0, (hipStream_t)stream, items_dev, n_items,
+                     force_variant());
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+size_t hg_wino_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t H, int32_t W) {
+  WinoPlan p;
+  if (!make_plan(B, K, N, H, W, p) || p.ksplit == 1) return 0;
+  return (size_t)p.ksplit * B * N * H * W * sizeof(float);
+}
+
+int hg_wino_conv2d(const float *in, const float *u, float *out, const float *iscale, const float *oscale,
+                   const float *bias, const float *noise_w, const float *noise_img, int32_t noise_S, float lrelu_slope,
+                   const float *addend, int32_t B, int32_t K, int32_t N, int32_t H, int32_t W, void *workspace,
+                   size_t workspace_bytes, void *stream) {
+  if (!in || !u || !out) return HG_EINVAL;
+  if ((noise_img != nullptr) != (noise_w != nullptr) || lrelu_slope < 0.f) return HG_EINVAL;
+  if (noise_img && (noise_S < H || noise_S < W || (noise_S & 1))) return HG_EINVAL;
+  if (addend && (iscale || oscale || noise_img || lrelu_slope > 0.f)) return HG_EINVAL;
+  WinoPlan p;
+  if (!make_plan(B, K, N, H, W, p)) return HG_EUNSUPPORTED;
+  if (p.ksplit > 1 && (!workspace || workspace_bytes < (size_t)p.ksplit * B * N * H * W * sizeof(float))) p.ksplit = 1;
+  WinoArgs a;
+  a.in = in; a.u = u; a.out = out; a.iscale = iscale; a.oscale = oscale; a.bias = bias; a.addend = addend;
+  a.noise_w = noise_w; a.noise_img = noise_img; a.noise_S = noise_S; a.slope = lrelu_slope;
+  a.B = B; a.K = K; a.N = N; a.H = H; a.W = W;
+  a.nblk = p.nblk; a.nch = p.nch; a.lTW = p.lTW; a.lTH = p.lTH; a.lNI = p.lNI;
+  a.tiles_w = p.tiles_w; a.tiles_h = p.tiles_h; a.bt_x = p.bt_x; a.bt_y = p.bt_y;
+  a.ksplit = p.ksplit; a.slab = (float *)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const bool fe = iscale != nullptr;
+  int rc = p.variant == 0 ? launch_wino<2, 2, 8>(a, p, fe, st) : launch_wino<1, 4, 4>(a, p, fe, st);
+  if (rc) return rc;
+  if (p.ksplit > 1) {
+    const long long total = (long long)B * N * H * W;   // H, W even -> a multiple of 4
+    long long nb = (total / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_wino_reduce, dim3((unsigned)nb), dim3(256), 0, st, a.slab, out, oscale, bias, noise_w, noise_img,
+                       addend, noise_S, lrelu_slope, total / 4, H * W, W, N, p.ksplit);
+    HG_LAUNCH_CHECK();
+  }
+  return HG_OK;
+}
+
+size_t hg_wino_wgrad_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t H, int32_t W) {
+  WgPlan p;
+  if (!make_wg_plan(B, K, N, H, W, p)) return 0;
+  return p.slab_bytes;
+}
+
+int hg_wino_wgrad_supported(int32_t B, int32_t K, int32_t N, int32_t H, int32_t W) {
+  WgPlan p;
+  if (!make_wg_plan(B, K, N, H, W, p)) return 0;
+  // 64 x 64 channel tiles: a layer with fewer channels on a side multiplies padding (and the transforms, done once per
+  // 64 x 64 tile, stop amortising); 4x4 maps and smaller are slab traffic rather than arithmetic
+  static const int min_c = getenv("HG_WINO_WG_MIN_C") ? atoi(getenv("HG_WINO_WG_MIN_C")) : 64;
+  static const int min_s = getenv("HG_WINO_WG_MIN_S") ? atoi(getenv("HG_WINO_WG_MIN_S")) : 8;
+  if (K < min_c || N < min_c || H < min_s || W < min_s) return 0;
+  return p.nchunks / p.splits >= 4;
+}
+
+int hg_wino_wgrad(const float *in, const float *gout, float *gw, int32_t B, int32_t K, int32_t N, int32_t H, int32_t W,
+                  void *workspace, size_t workspace_bytes, void *stream) {
+  if (!in || !gout || !gw || !workspace) return HG_EINVAL;
+  WgPlan p;
+  if (!make_wg_plan(B, K, N, H, W, p)) return HG_EUNSUPPORTED;
+  if (workspace_bytes < p.slab_bytes) return HG_EWORKSPACE;
+  WinoWgArgs a;
+  a.in = in; a.gout = gout; a.slab = (float *)workspace;
+  a.B = B; a.K = K; a.N = N; a.H = H; a.W = W;
+  a.ktiles = p.ktiles; a.splits = p.splits; a.nchunks = p.nchunks;
+  a.lPW = p.lPW; a.lPH = p.lPH; a.lPI = p.lPI; a.lcg = p.lcg; a.lrg = p.lrg;
+  a.Np = p.ntiles * 64; a.Kp = p.ktiles * 64;
+  hipStream_t st = (hipStream_t)stream;
+  constexpr size_t lds = 4 * (size_t)WG_OP * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void *)k_wino_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_wino_wgrad, dim3((unsigned)(p.ktiles * p.ntiles), (unsigned)p.splits), dim3(512), lds, st, a);
+  HG_LAUNCH_CHECK();
+  const long long nthr = (long long)N * (a.Kp / 4);
+  hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, a.slab, gw, N, K, a.Np, a.Kp,
+                     p.splits);
+  HG_LAUNCH_CHECK();
+  return HG_OK;
+}
+
+}  // extern "C"

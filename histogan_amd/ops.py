@@ -179,14 +179,7 @@ class _ModConvStage(torch.autograd.Function):
             nzt_ = wn_ = bn_ = None
             S = 0
         wt = C.pack_weights(w, C.PACK_FWD)
-        with on_device(x.device):
-            out = torch.empty((B, N, Hi, Wi), dtype=torch.float32, device=x.device)
-            nb = lib.hg_conv2d_workspace_bytes(B, K, N, Hi, Wi, k, 1, 0)
-            ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
-            p = lambda t: None if t is None else t.data_ptr()
-            check(lib.hg_modconv2d_fwd(xin.data_ptr(), wt.data_ptr(), out.data_ptr(), p(iscale), p(d), p(bn_), p(wn_),
-                                       p(nzt_), S, 0.2 if act else 0.0, B, K, N, Hi, Wi, k, p(ws), nb, _st(x)),
-                  'hg_modconv2d_fwd')
+        out = C.modconv_fwd_packed(xin, wt, N, k, iscale, d, bn_, wn_, nzt_, S, 0.2 if act else 0.0)
         ctx.save_for_backward(x, xin if upsample else None, style, w, d, out, nzt_, wn_, bn_)
         ctx.cfg = (bool(demod), bool(upsample), bool(act))
         return out
