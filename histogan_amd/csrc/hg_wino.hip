@@ -24,6 +24,11 @@
 #include "../../include/hg_conv.h"
 #include "../../include/hg_wino.h"
 
+// experiment knob: 1 = MFMAs and the next chunk's transform as separate scheduling regions (no interleaving)
+#ifndef HG_WINO_SPLIT_PHASE
+#define HG_WINO_SPLIT_PHASE 0
+#endif
+
 namespace {
 
 constexpr unsigned kOOB = 0xFFFFFFFFu;
@@ -127,22 +132,23 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x2][i][j][r] = 0.f;
 
-  float pd[16];
-  float ps = 1.f;
+  float pd[2][16];      // [register set][patch element]: the patch of chunk c lives in set c & 1
+  float ps[2] = {1.f, 1.f};
   float ua[2][2][NV];   // [register set][position][operand]
 
-  auto load_patch = [&](int c) __attribute__((always_inline)) {
+  auto load_patch = [&](int c, auto SET) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(inblk + (size_t)c * KC * HW);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      pd[4 * r] = buf_load(rx, vo[r][0], 0);
+      pd[S][4 * r] = buf_load(rx, vo[r][0], 0);
       const f32x2 m = buf_load2(rx, vo[r][1], 0);
-      pd[4 * r + 1] = m[0];
-      pd[4 * r + 2] = m[1];
-      pd[4 * r + 3] = buf_load(rx, vo[r][2], 0);
+      pd[S][4 * r + 1] = m[0];
+      pd[S][4 * r + 2] = m[1];
+      pd[S][4 * r + 3] = buf_load(rx, vo[r][2], 0);
     }
     if constexpr (FE) {
-      if (has_is) ps = buf_load(rs, so, c * KC * 4);
+      if (has_is) ps[S] = buf_load(rs, so, c * KC * 4);
     }
   };
   auto load_u = [&](int c, auto SET) __attribute__((always_inline)) {
@@ -163,12 +169,13 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
       }
     }
   };
-  // V = B^T d B of the prefetched patch into buffer `buf`
-  auto transform_store = [&](int buf) __attribute__((always_inline)) {
+  // V = B^T d B of patch set SET into buffer `buf`
+  auto transform_store = [&](int buf, auto SET) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
     float *Vb = smem + buf * VSZ + kc * TB + t;
     float d[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) d[e] = has_is ? pd[e] * ps : pd[e];
+    for (int e = 0; e < 16; ++e) d[e] = has_is ? pd[S][e] * ps[S] : pd[S][e];
     float q[16];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -207,10 +214,14 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
             acc[x2][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[S][x2][ks * TC + i], bv[x2][ks][j], acc[x2][i][j], 0, 0, 0);
   };
 
-  // K chunks of this split.  Two chunks per trip (V buffer / operand register set 0, then 1), and every load of the loop
-  // body is UNCONDITIONAL (past the end the chunk index is clamped: a redundant load nobody consumes): with loads behind
-  // branches the compiler has to assume the shortest path and waits for (almost) every outstanding load before the first
-  // MFMA of a chunk -- the global latency then runs in series with the MFMAs instead of under them.
+  // K chunks of this split, two phases per trip (V buffer / register sets 0, then 1).  Phase c: request the patch of chunk
+  // c + 2 FIRST (into the set the previous phase's transform just freed), multiply chunk c, transform the patch of chunk
+  // c + 1 (requested a whole phase ago: the compiler may interleave these additions with the MFMAs without exposing the
+  // load latency), then request the weights of chunk c + 2 into the set the MFMAs just released; ONE barrier.
+  // Every load of the loop body is UNCONDITIONAL (past the end the chunk index is clamped: a redundant load nobody
+  // consumes): with loads behind branches the compiler has to assume the shortest path and waits for (almost) every
+  // outstanding load before the first MFMA of a chunk.  sched_barrier at the phase boundaries: the scheduler otherwise
+  // hoists the first additions of the NEXT transform across the barrier, right behind the loads they consume.
   const int cps = (a.nch + a.ksplit - 1) / a.ksplit;
   const int c_begin = blockIdx.z * cps;
   const int c_end = c_begin + cps < a.nch ? c_begin + cps : a.nch;
@@ -220,27 +231,33 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   auto clampc = [&](int c) __attribute__((always_inline)) { return c < c_end ? c : c_end - 1; };
 
   if (nc > 0) {
-    load_patch(c_begin);
+    load_patch(c_begin, S0{});
     load_u(c_begin, S0{});
-    transform_store(0);
-    load_patch(clampc(c_begin + 1));
+    load_patch(clampc(c_begin + 1), S1{});
     load_u(clampc(c_begin + 1), S1{});
+    transform_store(0, S0{});
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     for (int c = c_begin; c + 1 < c_end; c += 2) {
-      // (sched_barrier: the scheduler otherwise hoists the first additions of the NEXT transform up to right behind the
-      // loads they consume -- an s_waitcnt for just-issued loads in the middle of the loop)
+      load_patch(clampc(c + 2), S0{});
+      __builtin_amdgcn_sched_barrier(0);   // (the loads stay in front: the scheduler would sink them behind the MFMAs)
       mfma_chunk(0, S0{});
-      __builtin_amdgcn_sched_barrier(0);   // the transform BEHIND the MFMAs: its patch was requested one phase ago, no sooner
-      transform_store(1);
-      load_patch(clampc(c + 2));
+#if HG_WINO_SPLIT_PHASE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      transform_store(1, S1{});
       load_u(clampc(c + 2), S0{});
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      mfma_chunk(1, S1{});
+      load_patch(clampc(c + 3), S1{});
       __builtin_amdgcn_sched_barrier(0);
-      transform_store(0);
-      load_patch(clampc(c + 3));
+      mfma_chunk(1, S1{});
+#if HG_WINO_SPLIT_PHASE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      transform_store(0, S0{});
       load_u(clampc(c + 3), S1{});
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
@@ -485,8 +502,13 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
   const int PWm = (1 << a.lPW) - 1, PHm = (1 << a.lPH) - 1;
   const int dtx = t & PWm, dty = (t >> a.lPW) & PHm, dimg = t >> (a.lPW + a.lPH);
   const int nrg = 1 << a.lrg, ncg = 1 << a.lcg;
-  const bool l_row0 = dty == 0, l_rowl = dty == PHm, l_tx0 = dtx == 0, l_txl = dtx == PWm;
-  const bool kok = k0 + ch < K, nok = n0 + ch < N;
+  // Zero padding = the byte offset 0xFFFFFFFF (the descriptor's range check answers 0.0).  Which elements of a patch are
+  // padding depends on the chunk (scalar: first / last row group, first / last column group) AND on the lane (its tile's
+  // row / column inside the chunk pattern): all-ones / zero MASKS, OR-ed onto the offsets -- no predicates, no branches
+  // (written as `cond ? kOOB : offset` the compiler builds exec-masked branches around every load).
+  const unsigned m_row0 = dty == 0 ? kOOB : 0u, m_rowl = dty == PHm ? kOOB : 0u;
+  const unsigned m_tx0 = dtx == 0 ? kOOB : 0u, m_txl = dtx == PWm ? kOOB : 0u;
+  const unsigned m_kbad = k0 + ch < K ? 0u : kOOB, m_nbad = n0 + ch < N ? 0u : kOOB;
   // patch element (r, c) relative to the chunk origin, against a base one row and one column BEFORE the image group
   unsigned vo[4][3];
 #pragma unroll
@@ -508,43 +530,51 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[x2][i][j][r] = 0.f;
 
-  float pd[16], gd[4];
-  auto load_chunk = [&](int c) __attribute__((always_inline)) {
+  float pd[2][16], gd[2][4];   // [register set][element]: chunk iteration `it` lives in set it & 1
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
+  auto load_chunk = [&](int c, auto SET) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
     // chunk -> (image group, row group, column group): scalar
     const int cg = c & (ncg - 1), rg = (c >> a.lcg) & (nrg - 1), ig = c >> (a.lcg + a.lrg);
     const int b0 = ig << a.lPI;
-    const bool top = rg == 0, bot = rg == nrg - 1, left = cg == 0, right = cg == ncg - 1;
-    const bool iok = b0 + dimg < a.B;
+    const unsigned top = rg == 0 ? kOOB : 0u, bot = rg == nrg - 1 ? kOOB : 0u;          // scalar masks
+    const unsigned left = cg == 0 ? kOOB : 0u, right = cg == ncg - 1 ? kOOB : 0u;
+    const unsigned m_img = (unsigned)((a.B - 1 - b0 - dimg) >> 31);                       // all ones when b0 + dimg >= B
     const unsigned soff = (unsigned)(((rg << a.lPH) * 2) * W + (cg << a.lPW) * 2) * 4u;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.in + (size_t)b0 * K * HW - (W + 1));
     const __amdgpu_buffer_rsrc_t rg_ = make_rsrc(a.gout + (size_t)b0 * N * HW);
-    const bool ri0 = top && l_row0, ri3 = bot && l_rowl, ci0 = left && l_tx0, ci3 = right && l_txl;
-    const bool ok = iok && kok;
+    const unsigned base = m_kbad | m_img;
+    const unsigned c0 = left & m_tx0, c3 = right & m_txl;
+    unsigned rm[4];
+    rm[0] = base | (top & m_row0);
+    rm[1] = rm[2] = base;
+    rm[3] = base | (bot & m_rowl);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool rinv = !ok || (r == 0 && ri0) || (r == 3 && ri3);
-      pd[4 * r] = buf_load(rx, (rinv || ci0) ? kOOB : vo[r][0], (int)soff);
-      const f32x2 m = buf_load2(rx, rinv ? kOOB : vo[r][1], (int)soff);
-      pd[4 * r + 1] = m[0];
-      pd[4 * r + 2] = m[1];
-      pd[4 * r + 3] = buf_load(rx, (rinv || ci3) ? kOOB : vo[r][2], (int)soff);
+      pd[S][4 * r] = buf_load(rx, vo[r][0] | rm[r] | c0, (int)soff);
+      const f32x2 m = buf_load2(rx, vo[r][1] | rm[r], (int)soff);
+      pd[S][4 * r + 1] = m[0];
+      pd[S][4 * r + 2] = m[1];
+      pd[S][4 * r + 3] = buf_load(rx, vo[r][2] | rm[r] | c3, (int)soff);
     }
-    const bool gok = iok && nok;
-    const f32x2 g0 = buf_load2(rg_, gok ? go : kOOB, (int)soff);
-    const f32x2 g1 = buf_load2(rg_, gok ? go + (unsigned)W * 4u : kOOB, (int)soff);
-    gd[0] = g0[0]; gd[1] = g0[1]; gd[2] = g1[0]; gd[3] = g1[1];
+    const unsigned gm = m_nbad | m_img;
+    const f32x2 g0 = buf_load2(rg_, go | gm, (int)soff);
+    const f32x2 g1 = buf_load2(rg_, (go + (unsigned)W * 4u) | gm, (int)soff);
+    gd[S][0] = g0[0]; gd[S][1] = g0[1]; gd[S][2] = g1[0]; gd[S][3] = g1[1];
   };
-  auto transform_store = [&](int buf) __attribute__((always_inline)) {
+  auto transform_store = [&](int buf, auto SET) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
     float *Mb = smem + buf * 2 * WG_OP + t * WG_P + ch;   // dM [position][tile][n]
     float *Vb = Mb + WG_OP;                               // V  [position][tile][k]
     // V = B^T d B
     float q[16];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      q[0 + c] = pd[0 + c] - pd[8 + c];
-      q[4 + c] = pd[4 + c] + pd[8 + c];
-      q[8 + c] = pd[8 + c] - pd[4 + c];
-      q[12 + c] = pd[4 + c] - pd[12 + c];
+      q[0 + c] = pd[S][0 + c] - pd[S][8 + c];
+      q[4 + c] = pd[S][4 + c] + pd[S][8 + c];
+      q[8 + c] = pd[S][8 + c] - pd[S][4 + c];
+      q[12 + c] = pd[S][4 + c] - pd[S][12 + c];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -554,8 +584,9 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
       Vb[(4 * r + 3) * 8 * WG_P] = q[4 * r + 1] - q[4 * r + 3];
     }
     // dM = A dY A^T,  A = [[1, 0], [1, 1], [1, -1], [0, -1]]
-    const float r0[2] = {gd[0], gd[1]}, r1[2] = {gd[0] + gd[2], gd[1] + gd[3]}, r2[2] = {gd[0] - gd[2], gd[1] - gd[3]},
-                r3[2] = {-gd[2], -gd[3]};
+    const float *g_ = gd[S];
+    const float r0[2] = {g_[0], g_[1]}, r1[2] = {g_[0] + g_[2], g_[1] + g_[3]}, r2[2] = {g_[0] - g_[2], g_[1] - g_[3]},
+                r3[2] = {-g_[2], -g_[3]};
     const float *rows[4] = {r0, r1, r2, r3};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -586,27 +617,33 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
       }
   };
 
-  // this block's chunks: split, split + splits, ...  (two per trip; loads unconditional with a clamped index, as k_wino)
+  // this block's chunks: a contiguous range (consecutive chunks continue along the tile row: the other half of the cache
+  // lines just fetched); two per trip, loads unconditional with a clamped index, as k_wino
   const int sp = blockIdx.y;
-  const int nc = sp < a.nchunks ? (a.nchunks - sp + a.splits - 1) / a.splits : 0;
-  auto chunk_of = [&](int it) __attribute__((always_inline)) { return sp + (it < nc ? it : nc - 1) * a.splits; };
+  const int cps = (a.nchunks + a.splits - 1) / a.splits;
+  const int c0 = sp * cps;
+  const int nc = c0 < a.nchunks ? (c0 + cps <= a.nchunks ? cps : a.nchunks - c0) : 0;
+  auto chunk_of = [&](int it) __attribute__((always_inline)) { return c0 + (it < nc ? it : nc - 1); };
   if (nc > 0) {
-    load_chunk(chunk_of(0));
-    transform_store(0);
-    load_chunk(chunk_of(1));
+    // phase `it`: request chunk it + 2 first, multiply chunk it, transform chunk it + 1 (requested a phase ago), barrier
+    load_chunk(chunk_of(0), S0{});
+    load_chunk(chunk_of(1), S1{});
+    transform_store(0, S0{});
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     for (int it = 0; it + 1 < nc; it += 2) {
-      mfma_chunk(0);
+      load_chunk(chunk_of(it + 2), S0{});
       __builtin_amdgcn_sched_barrier(0);
-      transform_store(1);
-      load_chunk(chunk_of(it + 2));
+      mfma_chunk(0);
+      transform_store(1, S1{});
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
-      mfma_chunk(1);
+      load_chunk(chunk_of(it + 3), S1{});
       __builtin_amdgcn_sched_barrier(0);
-      transform_store(0);
-      load_chunk(chunk_of(it + 3));
+      mfma_chunk(1);
+      transform_store(0, S0{});
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
@@ -627,21 +664,27 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
           sb[((size_t)(2 * wave + x2) * a.Np + n0 + 32 * i + mrow(r, lk)) * a.Kp + k0 + 32 * j + lm] = acc[x2][i][j][r];
 }
 
-// gw[n][k][3][3] = G^T (sum_s slab[s][.][n][k]) G.  One thread per (n, 4 consecutive k): 16-byte loads, fixed split order.
+// gw[n][k][3][3] = G^T (sum_s slab[s][.][n][k]) G.  Block = (n, 4 * KQ consecutive k), KQ = 256 / SG: thread (kq = 4 k's,
+// sg = one of SG split groups) sums its splits (16-byte loads, sixteen independent streams), applies the (linear) transform
+// to its partial sum, and the SG groups combine in LDS in fixed order (deterministic); 36 * KQ contiguous floats per block
+// are stored.  SG = 32 / 8 / 1 by the number of splits (many splits: few (n, k); few splits: many).
+template <int SG>
 __global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float *__restrict__ slab, float *__restrict__ gw, int N, int K,
                                                            int Np, int Kp, int splits) {
-  const int kq = Kp / 4;
-  const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (id >= (long long)N * kq) return;
-  const int n = (int)(id / kq), k4 = (int)(id % kq) * 4;
+  constexpr int KQ = 256 / SG;
+  __shared__ float part[SG][KQ][37];
+  const int tid = threadIdx.x, kq = tid % KQ, sg = tid / KQ;
+  const int n = blockIdx.y, kb = blockIdx.x * (4 * KQ), k4 = kb + kq * 4;
   const size_t pstride = (size_t)Np * Kp, sstride = 16 * pstride;
   const float *p = slab + (size_t)n * Kp + k4;
   f32x4 u[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) u[e] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int s_ = 0; s_ < splits; ++s_) {
+  if (k4 < Kp) {
+    for (int s_ = sg; s_ < splits; s_ += SG) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) u[e] += *reinterpret_cast<const f32x4 *>(p + (size_t)s_ * sstride + e * pstride);
+      for (int e = 0; e < 16; ++e) u[e] += *reinterpret_cast<const f32x4 *>(p + (size_t)s_ * sstride + e * pstride);
+    }
   }
   // rows: G^T u (3 x 4), G^T = [[1, .5, .5, 0], [0, .5, -.5, 0], [0, .5, .5, 1]]; then the same along the columns
   f32x4 tq[3][4];
@@ -652,22 +695,26 @@ __global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float *__restri
     tq[1][c] = hd;
     tq[2][c] = hs + u[12 + c];
   }
-  f32x4 g[3][3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const f32x4 hs = 0.5f * (tq[r][1] + tq[r][2]), hd = 0.5f * (tq[r][1] - tq[r][2]);
-    g[r][0] = tq[r][0] + hs;
-    g[r][1] = hd;
-    g[r][2] = hs + tq[r][3];
+    const f32x4 g0 = tq[r][0] + hs, g1 = hd, g2 = hs + tq[r][3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      part[sg][kq][e * 9 + 3 * r + 0] = g0[e];
+      part[sg][kq][e * 9 + 3 * r + 1] = g1[e];
+      part[sg][kq][e * 9 + 3 * r + 2] = g2[e];
+    }
   }
+  __syncthreads();
+  // output q of the block's 4 KQ k x 9: k_local = q / 9 -> (kq = k_local >> 2, e = k_local & 3), tap = q % 9
+  for (int q = tid; q < 36 * KQ; q += 256) {
+    const int kl = q / 9, rc = q - kl * 9;
+    if (kb + kl >= K) break;
+    float v = 0.f;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if (k4 + e >= K) break;
-    float *dst = gw + ((size_t)n * K + k4 + e) * 9;
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) dst[3 * r + c] = g[r][c][e];
+    for (int g = 0; g < SG; ++g) v += part[g][kl >> 2][(kl & 3) * 9 + rc];
+    gw[((size_t)n * K + kb) * 9 + q] = v;
   }
 }
 
@@ -883,9 +930,10 @@ int hg_wino_wgrad_supported(int32_t B, int32_t K, int32_t N, int32_t H, int32_t 
   WgPlan p;
   if (!make_wg_plan(B, K, N, H, W, p)) return 0;
   // 64 x 64 channel tiles: a layer with fewer channels on a side multiplies padding (and the transforms, done once per
-  // 64 x 64 tile, stop amortising); 4x4 maps and smaller are slab traffic rather than arithmetic
+  // 64 x 64 tile, stop amortising: 0.75x at 32 -> 64); 2x2 maps are slab traffic rather than arithmetic (0.84-0.95x);
+  // measured 1.25-1.9x elsewhere (tools/wino_probe.py, profiles/r05_wino_probe_v3.txt)
   static const int min_c = getenv("HG_WINO_WG_MIN_C") ? atoi(getenv("HG_WINO_WG_MIN_C")) : 64;
-  static const int min_s = getenv("HG_WINO_WG_MIN_S") ? atoi(getenv("HG_WINO_WG_MIN_S")) : 8;
+  static const int min_s = getenv("HG_WINO_WG_MIN_S") ? atoi(getenv("HG_WINO_WG_MIN_S")) : 4;
   if (K < min_c || N < min_c || H < min_s || W < min_s) return 0;
   return p.nchunks / p.splits >= 4;
 }
@@ -912,9 +960,15 @@ int hg_wino_wgrad(const float *in, const float *gout, float *gw, int32_t B, int3
   }
   hipLaunchKernelGGL(k_wino_wgrad, dim3((unsigned)(p.ktiles * p.ntiles), (unsigned)p.splits), dim3(512), lds, st, a);
   HG_LAUNCH_CHECK();
-  const long long nthr = (long long)N * (a.Kp / 4);
-  hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, a.slab, gw, N, K, a.Np, a.Kp,
-                     p.splits);
+  if (p.splits >= 16)
+    hipLaunchKernelGGL(k_wino_wgrad_reduce<32>, dim3((unsigned)((a.Kp + 31) / 32), (unsigned)N), dim3(256), 0, st, a.slab, gw, N, K,
+                       a.Np, a.Kp, p.splits);
+  else if (p.splits >= 4)
+    hipLaunchKernelGGL(k_wino_wgrad_reduce<8>, dim3((unsigned)((a.Kp + 127) / 128), (unsigned)N), dim3(256), 0, st, a.slab, gw, N, K,
+                       a.Np, a.Kp, p.splits);
+  else
+    hipLaunchKernelGGL(k_wino_wgrad_reduce<1>, dim3((unsigned)((a.Kp + 1023) / 1024), (unsigned)N), dim3(256), 0, st, a.slab, gw, N,
+                       K, a.Np, a.Kp, p.splits);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }

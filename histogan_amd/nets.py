@@ -150,6 +150,11 @@ class GeneratorBlock(nn.Module):
         # (d before the convolution: the backward then reaches the convolution's weight gradient first, which writes the flat
         # gradient slot outright, and the demodulation's weight term accumulates into it -- conv.direct_weight_term)
         d = conv.demod_coeff(style) if conv.demod else None
+        if (ops.FUSED_DNL and conv.stride == 1 and conv.dilation == 1 and conv.kernel in (1, 3) and x.is_cuda
+                and nzt.shape[-1] % 2 == 0 and conv.weight.dtype == torch.float32):
+            # modulation prologue (materialised: the weight gradient's operand), then convolution + demodulation + noise +
+            # LeakyReLU as one launch (ops._ConvDnl)
+            return ops.conv_dnl(ops.modulate(x, style, upsample), conv.weight, d, nzt, to_noise.weight, to_noise.bias)
         c = conv.contract(x, style, upsample)
         return ops.demod_noise_lrelu(c, d, nzt, to_noise.weight, to_noise.bias)
 

@@ -140,6 +140,63 @@ def demod_noise_lrelu(conv, d, nzt, wn, bn):
     return _DemodNoiseLrelu.apply(conv, d, nzt, wn, bn)
 
 
+FUSED_DNL = os.environ.get('HG_FUSED_DNL', '1') != '0'   # conv + demodulation + noise + LeakyReLU as one forward launch in training
+
+
+class _ConvDnl(torch.autograd.Function):
+    """out = lrelu_0.2(d[b,o] * conv(xm, W) + wn[o] * nzt[b,i,j] + bn[o]) on the already MODULATED input xm, as ONE launch
+    (the fused epilogue of hg_wino_conv2d / hg_modconv2d_fwd): the training forward of a generator stage
+    (histoGAN/histoGAN.py:431-439, 465-476) without the separate k_dnl_fwd pass and without storing the convolution output.
+    Backward: k_dnl_bwd recovers conv * d from `out` (conv = NULL form), then the data gradient and the weight gradient
+    (xm is materialised, so the weight gradient needs no modulation of its own -- the cost that made the fully fused stage
+    lose, _ModConvStage).  First order only, like _DemodNoiseLrelu."""
+
+    @staticmethod
+    def forward(ctx, xm, w, d, nzt, wn, bn):
+        from . import conv as C
+        _need_gpu(xm, 'conv_dnl')
+        xm_, w_ = _f32c(xm.detach()), _f32c(w.detach())
+        d_ = None if d is None else _f32c(d.detach())
+        nzt_, wn_, bn_ = _f32c(nzt.detach()), _f32c(wn.detach().reshape(-1)), _f32c(bn.detach())
+        N, k = w_.shape[0], w_.shape[2]
+        if xm_.shape[2] != xm_.shape[3]:
+            raise ValueError('square feature maps only (the noise permute of the reference needs H == W)')
+        out = C.modconv_fwd_packed(xm_, C.pack_weights(w_, C.PACK_FWD), N, k, None, d_, bn_, wn_, nzt_, nzt_.shape[-1], 0.2)
+        ctx.save_for_backward(xm, w, d_, nzt_, out, wn_, bn_)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from . import conv as C
+        xm, w, d, nzt_, out, wn_, bn_ = ctx.saved_tensors
+        g = _f32c(g.detach())
+        B, N, H, _ = out.shape
+        K, k = w.shape[1], w.shape[2]
+        S = nzt_.shape[-1]
+        with on_device(out.device):
+            gconv = torch.empty_like(out)
+            gd = None if d is None else torch.empty_like(d)
+            gw_p = torch.empty((B, N), dtype=torch.float32, device=out.device)
+            gb_p = torch.empty((B, N), dtype=torch.float32, device=out.device)
+            ws, n = _ws(out, B, N, H, H)
+            check(lib.hg_demod_noise_lrelu_bwd(g.data_ptr(), out.data_ptr(), None, None if d is None else d.data_ptr(),
+                                               nzt_.data_ptr(), wn_.data_ptr(), bn_.data_ptr(), gconv.data_ptr(),
+                                               None if gd is None else gd.data_ptr(), gw_p.data_ptr(), gb_p.data_ptr(),
+                                               B, N, H, S, ws.data_ptr(), n, _st(out)), 'hg_demod_noise_lrelu_bwd')
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = C.conv_dgrad_packed(gconv, C.pack_weights(_f32c(w.detach()), C.PACK_DGRAD), K, xm.shape[2], xm.shape[3], k)
+        if ctx.needs_input_grad[1] and not C._skip_wgrad and not C._direct_wgrad(w, xm, gconv, 1):
+            gw = C.conv_wgrad(_f32c(xm.detach()), gconv, k)
+        return gx, gw, gd, None, gw_p.sum(0).reshape(-1, 1), gb_p.sum(0)
+
+
+def conv_dnl(xm, w, d, nzt, wn, bn):
+    """lrelu_0.2(d * conv(xm, w) + wn * nzt + bn) in one forward launch -- see _ConvDnl."""
+    return _ConvDnl.apply(xm, w, d, nzt, wn, bn)
+
+
 class _ModConvStage(torch.autograd.Function):
     """One generator convolution stage as a single forward launch (hg_modconv2d_fwd):
 

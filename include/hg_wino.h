@@ -59,7 +59,7 @@ int hg_wino_conv2d(const float *in, const float *u, float *out, const float *isc
 /* Weight gradient of that convolution on the same transform:  gw = G^T [ sum_tiles (A gout A^T) . (B^T in B) ] G
  *   in (B,K,H,W), gout (B,N,H,W), gw (N,K,3,3) contiguous, fully written; deterministic (per-split slabs in the
  *   workspace, summed in fixed order).  Maps whose sides are 2 x a power of two.  hg_wino_wgrad_supported: served AND
- *   expected to beat hg_conv2d_wgrad (>= 64 channels on both sides, maps >= 8x8). */
+ *   expected to beat hg_conv2d_wgrad (>= 64 channels on both sides, maps >= 4x4). */
 int hg_wino_wgrad_supported(int32_t B, int32_t K, int32_t N, int32_t H, int32_t W);
 size_t hg_wino_wgrad_workspace_bytes(int32_t B, int32_t K, int32_t N, int32_t H, int32_t W);
 int hg_wino_wgrad(const float *in, const float *gout, float *gw, int32_t B, int32_t K, int32_t N, int32_t H, int32_t W,

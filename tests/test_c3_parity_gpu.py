@@ -140,18 +140,20 @@ def test_c3_generator_matches_fp64_oracle(gpu_device):
     hists = torch.randn(B, 2, LAT, generator=g).to(dev).requires_grad_(True)
     noise = torch.rand(B, S_, S_, 1, generator=g).to(dev)
     go = torch.randn(B, 3, S_, S_, generator=g).to(dev)
-    masks, orig_dnl = [], ops.demod_noise_lrelu
+    masks, orig_dnl, orig_cdnl = [], ops.demod_noise_lrelu, ops.conv_dnl
 
-    def recording_dnl(*a):
-        out = orig_dnl(*a)
-        masks.append(out.detach() > 0)
-        return out
+    def recording(orig):       # the stage's activation comes from ops.conv_dnl (one launch) or ops.demod_noise_lrelu
+        def f(*a):
+            out = orig(*a)
+            masks.append(out.detach() > 0)
+            return out
+        return f
 
-    ops.demod_noise_lrelu = recording_dnl
+    ops.demod_noise_lrelu, ops.conv_dnl = recording(orig_dnl), recording(orig_cdnl)
     try:
         rgb = G(styles, hists, noise)
     finally:
-        ops.demod_noise_lrelu = orig_dnl
+        ops.demod_noise_lrelu, ops.conv_dnl = orig_dnl, orig_cdnl
     assert len(masks) == 2 * len(G.blocks)
     grads = torch.autograd.grad(rgb, [styles, hists] + [params[n] for n in names], go)
     with LreluMasks(masks) as lm:

@@ -14,7 +14,7 @@ skip = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 c = sqlite3.connect(db)
 rows = c.execute('select d.start, d.end, s.kernel_name from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s '
                  'on d.kernel_id = s.id order by d.start').fetchall()
-MFMA = re.compile(r'k_conv|k_wgradI|k_hist_fwd|k_hist_bwd|Cijk_')
+MFMA = re.compile(r'k_conv|k_wgradI|k_winoI|k_wino_wgradE|k_hist_fwd|k_hist_bwd|Cijk_')
 opt = [i for i, r in enumerate(rows) if 'k_diffgrad' in r[2]]
 per_step = len(opt) // steps                       # optimizer launches per step (2: D and G)
 first = opt[skip * per_step - 1] + 1               # after the last optimizer launch of step `skip`
