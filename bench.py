@@ -117,7 +117,7 @@ def g_layers(size, cap):
 G_LAYERS = g_layers(256, 16)
 
 
-TRAFFIC_FILE = 'r04_pmc_traffic.json'
+TRAFFIC_FILE = 'r05_pmc_traffic.json'
 
 
 def source_digest(name):
@@ -187,10 +187,28 @@ def recorded_value(key):
     return None
 
 
+def _time_calls(calls, iters):
+    ts = []
+    for fn in calls:
+        if fn is None:
+            ts.append(None)
+            continue
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / iters * 1e-3)
+    return ts
+
+
 def conv_kernel_times(dev, B, iters=6, layers=None):
-    """HIP events (torch's current stream == the stream the C ABI launches on) around hg_conv2d_fwd /
-    hg_conv2d_dgrad / hg_conv2d_wgrad with preallocated buffers, for every generator 3x3 layer.
-    Returns {layer: (flops, t_fwd, t_dgrad, t_wgrad)} in seconds per launch."""
+    """HIP events (torch's current stream == the stream the C ABI launches on) around the C-ABI launches of every generator
+    3x3 layer with preallocated buffers: the direct implicit GEMM (hg_conv2d_fwd / _dgrad / _wgrad) and, where the library
+    dispatches it (hg_wino_supported / hg_wino_wgrad_supported), the Winograd form (hg_wino_conv2d / hg_wino_wgrad).
+    Returns {layer: dict(flops, direct=(t_fwd, t_dgrad, t_wgrad), wino=(t or None, ...))} in seconds per launch."""
     import ctypes
     from histogan_amd import conv as C
     from histogan_amd._lib import lib, check
@@ -201,46 +219,65 @@ def conv_kernel_times(dev, B, iters=6, layers=None):
         w = torch.randn(N, K, 3, 3, device=dev) / (K * 9) ** 0.5
         go = torch.randn(B, N, S, S, device=dev)
         y, gx, gw = torch.empty_like(go), torch.empty_like(x), torch.empty_like(w)
-        wf, wd = C.pack_weights(w, C.PACK_FWD), C.pack_weights(w, C.PACK_DGRAD)
+        wf, wd = C._pack_weights(w, C.PACK_FWD), C._pack_weights(w, C.PACK_DGRAD)
         nf = lib.hg_conv2d_workspace_bytes(B, K, N, S, S, 3, 1, 0)
         nd = lib.hg_conv2d_workspace_bytes(B, N, K, S, S, 3, 1, 1)
         nw = lib.hg_conv2d_wgrad_workspace_bytes(B, K, N, S, S, 3, 1)
-        ws = torch.empty(max(nf, nd, nw, 4), dtype=torch.uint8, device=dev)
-        calls = (
+        wnf, wnd = lib.hg_wino_workspace_bytes(B, K, N, S, S), lib.hg_wino_workspace_bytes(B, N, K, S, S)
+        wnw = lib.hg_wino_wgrad_workspace_bytes(B, K, N, S, S)
+        ws = torch.empty(max(nf, nd, nw, wnf, wnd, wnw, 4), dtype=torch.uint8, device=dev)
+        direct = _time_calls((
             lambda: check(lib.hg_conv2d_fwd(x.data_ptr(), wf.data_ptr(), y.data_ptr(), None, None, None, B, K, N, S, S,
                                             3, 1, ws.data_ptr(), ws.numel(), st), 'fwd'),
             lambda: check(lib.hg_conv2d_dgrad(go.data_ptr(), wd.data_ptr(), gx.data_ptr(), None, None, B, N, K, S, S,
                                               3, 1, ws.data_ptr(), ws.numel(), st), 'dgrad'),
             lambda: check(lib.hg_conv2d_wgrad(x.data_ptr(), go.data_ptr(), gw.data_ptr(), None, None, B, K, N, S, S,
-                                              3, 1, ws.data_ptr(), ws.numel(), st), 'wgrad'))
-        ts = []
-        for fn in calls:
-            fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1) / iters * 1e-3)
-        out[(K, N, S)] = (2.0 * B * S * S * K * N * 9, *ts)
+                                              3, 1, ws.data_ptr(), ws.numel(), st), 'wgrad')), iters)
+        uf = C._wino_pack(w, C.PACK_FWD) if C.wino_supported(B, K, N, S, S) else False
+        ud = C._wino_pack(w, C.PACK_DGRAD) if C.wino_supported(B, N, K, S, S) else False
+        wino = _time_calls((
+            (lambda: check(lib.hg_wino_conv2d(x.data_ptr(), uf.data_ptr(), y.data_ptr(), None, None, None, None, None, 0, 0.0,
+                                              None, B, K, N, S, S, ws.data_ptr(), ws.numel(), st), 'wino fwd')) if uf is not False else None,
+            (lambda: check(lib.hg_wino_conv2d(go.data_ptr(), ud.data_ptr(), gx.data_ptr(), None, None, None, None, None, 0, 0.0,
+                                              None, B, N, K, S, S, ws.data_ptr(), ws.numel(), st), 'wino dgrad')) if ud is not False else None,
+            (lambda: check(lib.hg_wino_wgrad(x.data_ptr(), go.data_ptr(), gw.data_ptr(), B, K, N, S, S, ws.data_ptr(), ws.numel(),
+                                             st), 'wino wgrad')) if C.wino_wgrad_supported(B, K, N, S, S) else None), iters)
+        out[(K, N, S)] = dict(flops=2.0 * B * S * S * K * N * 9, direct=tuple(direct), wino=tuple(wino))
     return out
 
 
+WINO_FLOP_RATIO = 16.0 / 36.0   # executed multiplications of F(2x2,3x3) per multiplication of the direct 3x3 convolution
+
+
+def wino_line(kernel, direct_flops, t, extra=None):
+    """A roofline entry of a Winograd launch: `achieved` / `frac` count the MFMA flops the kernel EXECUTES (16 products per
+    2x2 output tile, input and output channel); what a direct convolution would have to sustain for the same launch time is
+    the separate key `direct_equivalent_tflops` -- a speed-up measure, not a roofline fraction."""
+    ex = direct_flops * WINO_FLOP_RATIO
+    d = {'kernel': kernel, 'bound': 'mfma', 'achieved': ex / t / 1e12, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+         'frac': ex / t / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': t * 1e3, 'flops_per_launch': ex,
+         'direct_equivalent_tflops': direct_flops / t / 1e12, 'direct_conv_flops_per_launch': direct_flops}
+    if extra:
+        d.update(extra)
+    return d
+
+
 def leading_kernel_lines(dev, B, ct, size, cap):
-    """Stand-alone lines for the two k_conv instantiations that lead the step's kernel trace (profiles/r04_train_c3_kernel_stats.md:
-    KC = 4 / FE = false, 10.6 % of the kernel time; the fused-extras FE = true one, 8.1 %) -- the headline roofline launch is
-    the KC = 2 instantiation, only the 4th by step time.  (a) KC = 4, FE = false: the 128 x 128 tile with 4-channel K
-    chunks that the deep-K 3x3 layers take; timed at 512 -> 256 channels, 32 x 32 (at 256^2 / capacity 16) through
-    hg_conv2d_fwd (the number conv_kernel_times already measured).  (b) FE = true: the no-autograd generator stage (hg_modconv2d_fwd: modulation while staging,
-    convolution, demodulation, noise, LeakyReLU in one launch) at the roofline launch's own layer, HIP events around
-    ops.modconv_stage under no_grad."""
+    """Stand-alone lines for the other launches that lead the step's kernel trace next to the headline roofline launch:
+    (a) the Winograd data gradient at 512 -> 256 channels, 32 x 32 (hg_wino_conv2d on the transposed / flipped operand);
+    (b) the no-autograd generator stage (ops.modconv_stage: modulation while the patches are loaded, convolution,
+    demodulation, noise, LeakyReLU in ONE hg_wino_conv2d launch, plus its demodulation-coefficient launches) at the roofline
+    layer; (c) the DIRECT k_conv at 512 -> 256, 32 x 32, the kernel that still runs every 1x1 / stride-2 / few-channel layer."""
     from histogan_amd import ops
     out = []
     key = (32 * cap, 16 * cap, size // 8)
     if key in ct:
-        fl, tf = ct[key][0], ct[key][1]
-        out.append({'kernel': 'k_conv<KC=4, FE=false> (hg_conv2d_fwd) at %d->%d ch, %dx%d, batch %d' % (*key, key[2], B), 'bound': 'mfma',
+        fl = ct[key]['flops']
+        if ct[key]['wino'][1] is not None:
+            out.append(wino_line('k_wino (hg_wino_conv2d, data gradient) at %d->%d ch, %dx%d, batch %d' % (key[1], key[0], key[2], key[2], B),
+                                 fl, ct[key]['wino'][1]))
+        tf = ct[key]['direct'][0]
+        out.append({'kernel': 'k_conv<KC=4, FE=false> (hg_conv2d_fwd, direct implicit GEMM) at %d->%d ch, %dx%d, batch %d' % (*key, key[2], B), 'bound': 'mfma',
                     'achieved': fl / tf / 1e12, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / tf / 1e12 / FP32_PEAK_TFLOPS,
                     'launch_ms': tf * 1e3})
     K, N, S = 16 * cap, 8 * cap, size // 4
@@ -260,10 +297,14 @@ def leading_kernel_lines(dev, B, ct, size, cap):
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / 6 * 1e-3
     fl = 2.0 * B * S * S * K * N * 9
-    out.append({'kernel': 'k_conv<FE=true> (hg_modconv2d_fwd: modulate + conv + demodulate + noise + LeakyReLU, incl. its '
-                          'demodulation-coefficient launches) at %d->%d ch, %dx%d, batch %d' % (K, N, S, S, B), 'bound': 'mfma',
-                'achieved': fl / t / 1e12, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / t / 1e12 / FP32_PEAK_TFLOPS,
-                'launch_ms': t * 1e3})
+    from histogan_amd import conv as C
+    name = ('generator stage (ops.modconv_stage: modulate + conv + demodulate + noise + LeakyReLU, incl. its demodulation-'
+            'coefficient launches) at %d->%d ch, %dx%d, batch %d' % (K, N, S, S, B))
+    if C.wino_supported(B, K, N, S, S):
+        out.append(wino_line('k_wino<FE=true> (hg_wino_conv2d) ' + name, fl, t))
+    else:
+        out.append({'kernel': 'k_conv<FE=true> (hg_modconv2d_fwd) ' + name, 'bound': 'mfma', 'achieved': fl / t / 1e12,
+                    'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': fl / t / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': t * 1e3})
     return out
 
 
@@ -532,19 +573,35 @@ def launch_ranks(n, argv, json_out, timeout=None):
     for r in range(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=rank_env(os.environ, r, n, port),
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    t_end = None if timeout is None else time.time() + timeout
-    rc, out0 = 0, b''
+    # Supervise EVERY rank: when one exits non-zero (out of memory, bad device) the others would sit in the rendezvous or a
+    # collective for ever -- they are killed and its exit code returned (what torch.distributed.run does for its workers).
+    import threading
+    chunks = []
+    rd = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    t_end = time.time() + (timeout if timeout is not None else 3600.0)
+    rc = 0
     try:
-        out0, _ = procs[0].communicate(timeout=timeout)
-        for p in procs:
-            p.wait(timeout=None if t_end is None else max(1.0, t_end - time.time()))
-            rc = rc or p.returncode
-    except subprocess.TimeoutExpired:
-        rc = 124
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > t_end:
+                rc = 124
+                break
+            time.sleep(0.05)
     finally:
         for p in procs:              # exactly the processes started here
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            p.wait()
+    rd.join(timeout=10)
+    out0 = b''.join(c for c in chunks if c)
     lines = [l for l in out0.decode(errors='replace').splitlines() if l.strip()]
     if rc == 0 and lines:
         print(lines[-1], file=json_out, flush=True)
@@ -715,23 +772,50 @@ def main():
     if args.workload in ('train', 'rehistogan'):
         ct = conv_kernel_times(dev, args.batch, layers=g_layers(args.size, args.capacity))
         rl = (16 * args.capacity, 8 * args.capacity, args.size // 4)        # 256 -> 128 channels at a quarter of the image size
-        fl, tf, td, tw = ct[rl]
-        tot = [sum(v[i] for v in ct.values()) for i in range(4)]
-        roof = {'kernel': 'k_conv<128ch x 128px tile, 3x3, stride 1> (hg_conv2d_fwd) at %d->%d ch, %dx%d, batch %d' % (rl[0], rl[1], rl[2], rl[2], args.batch),
-                'bound': 'mfma', 'achieved': fl / tf / 1e12, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': fl / tf / 1e12 / FP32_PEAK_TFLOPS,
-                'traffic': recorded_traffic('k_conv_fwd_256_128_64_b32')[0] if (args.batch, rl) == (32, (256, 128, 64)) else None,
+        fl = ct[rl]['flops']
+        tf, td, tw = ct[rl]['direct']
+        wf_, wd_, ww_ = ct[rl]['wino']
+        where = 'at %d->%d ch, %dx%d, batch %d' % (rl[0], rl[1], rl[2], rl[2], args.batch)
+        direct_line = {'kernel': 'k_conv<128ch x 128px tile, 3x3, stride 1> (hg_conv2d_fwd, direct implicit GEMM: the kernel the '
+                                 'Winograd form replaced on this layer) ' + where, 'bound': 'mfma',
+                       'achieved': fl / tf / 1e12, 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                       'frac': fl / tf / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': tf * 1e3, 'flops_per_launch': fl,
+                       'traffic': recorded_traffic('k_conv_fwd_256_128_64_b32')[0] if (args.batch, rl) == (32, (256, 128, 64)) else None,
+                       'traffic_source': recorded_traffic('k_conv_fwd_256_128_64_b32')[1],
+                       'wgrad': {'kernel': 'k_wgrad (hg_conv2d_wgrad), same layer', 'achieved': fl / tw / 1e12,
+                                 'frac': fl / tw / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': tw * 1e3}}
+        alg_bytes = 4.0 * (args.batch * rl[0] * rl[2] ** 2 + args.batch * rl[1] * rl[2] ** 2 + 16 * rl[0] * rl[1])
+        if wf_ is not None:
+            roof = wino_line('k_wino<64 ch x 64 tiles x 16 positions> (hg_wino_conv2d: Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32) ' + where,
+                             fl, wf_, {
+                'traffic': recorded_traffic('k_wino_fwd_256_128_64_b32')[0] if (args.batch, rl) == (32, (256, 128, 64)) else None,
                 'traffic_unit': 'bytes/launch (FETCH_SIZE + WRITE_SIZE)',
-                'traffic_source': recorded_traffic('k_conv_fwd_256_128_64_b32')[1],
-                'launch_ms': tf * 1e3, 'flops_per_launch': fl,
-                'algorithmic_bytes_per_launch': 4.0 * (args.batch * rl[0] * rl[2] ** 2 + args.batch * rl[1] * rl[2] ** 2 + 9 * rl[0] * rl[1]),
-                'wgrad': {'kernel': 'k_wgrad (hg_conv2d_wgrad), same layer', 'achieved': fl / tw / 1e12,
-                          'frac': fl / tw / 1e12 / FP32_PEAK_TFLOPS, 'launch_ms': tw * 1e3},
-                'generator_3x3_layers': {'flops_per_pass': tot[0],
-                                         'fwd_tflops': tot[0] / tot[1] / 1e12, 'dgrad_tflops': tot[0] / tot[2] / 1e12,
-                                         'wgrad_tflops': tot[0] / tot[3] / 1e12,
-                                         'fwd_ms': tot[1] * 1e3, 'dgrad_ms': tot[2] * 1e3, 'wgrad_ms': tot[3] * 1e3},
-                'hist': hist_roof}
+                'traffic_source': recorded_traffic('k_wino_fwd_256_128_64_b32')[1],
+                'algorithmic_bytes_per_launch': alg_bytes})
+            if ww_ is not None:
+                roof['wgrad'] = wino_line('k_wino_wgrad + k_wino_wgrad_reduce (hg_wino_wgrad), same layer', fl, ww_)
+            if wd_ is not None:
+                roof['dgrad'] = wino_line('k_wino (hg_wino_conv2d on the data-gradient operand), same layer', fl, wd_)
+            roof['direct_kernel'] = direct_line
+        else:
+            roof = direct_line
+            roof['algorithmic_bytes_per_launch'] = alg_bytes
+        # the generator's fourteen 3x3 layers as the library dispatches them (Winograd where hg_wino_*_supported, else direct)
+        disp = [sum((v['wino'][i] if v['wino'][i] is not None else v['direct'][i]) for v in ct.values()) for i in range(3)]
+        dire = [sum(v['direct'][i] for v in ct.values()) for i in range(3)]
+        flp = sum(v['flops'] for v in ct.values())
+        roof['generator_3x3_layers'] = {
+            'direct_conv_flops_per_pass': flp,
+            'as_dispatched': {'fwd_ms': disp[0] * 1e3, 'dgrad_ms': disp[1] * 1e3, 'wgrad_ms': disp[2] * 1e3,
+                              'fwd_direct_equivalent_tflops': flp / disp[0] / 1e12, 'dgrad_direct_equivalent_tflops': flp / disp[1] / 1e12,
+                              'wgrad_direct_equivalent_tflops': flp / disp[2] / 1e12,
+                              'layers_on_winograd': {'fwd': sum(v['wino'][0] is not None for v in ct.values()),
+                                                     'dgrad': sum(v['wino'][1] is not None for v in ct.values()),
+                                                     'wgrad': sum(v['wino'][2] is not None for v in ct.values()), 'of': len(ct)}},
+            'direct_kernels': {'fwd_ms': dire[0] * 1e3, 'dgrad_ms': dire[1] * 1e3, 'wgrad_ms': dire[2] * 1e3,
+                               'fwd_tflops': flp / dire[0] / 1e12, 'dgrad_tflops': flp / dire[1] / 1e12,
+                               'wgrad_tflops': flp / dire[2] / 1e12}}
+        roof['hist'] = hist_roof
         try:
             roof['leading_kernels'] = leading_kernel_lines(dev, args.batch, ct, args.size, args.capacity)
         except Exception as e:

@@ -230,7 +230,7 @@ def cached(w, tag, compute):
     st = _stamp(w, owner)
     if hit is not None and hit[0] == st:
         if tag == 'wsq':
-            _await_pack(owner, w.device)
+            _await_pack(owner, w.device, key)
         return hit[1]
     if tag == 'wsq' and PACK_MULTI and w.is_cuda and _pack_owner(owner, w.device):
         # the batched packing launch of this weight's flat buffer also leaves sum_taps W^2 of every weight (hg_pack_item.wsq)
@@ -250,7 +250,7 @@ def pack_weights(w, mode):
         hit = _cache.get((key, mode))
         st = _stamp(w, owner)
         if hit is not None and hit[0] == st:
-            _await_pack(owner, w.device)
+            _await_pack(owner, w.device, key)
             return hit[1]
         # A registered (training) weight needs both operands once per optimizer step, and so do all its siblings in the
         # same flat buffer: ONE launch packs every convolution weight of that buffer (hg_conv_pack_weights_multi) the
@@ -288,9 +288,17 @@ def build_pack_plans(device):
         _pack_owner(owner, device, launch=False)
 
 
-def _pack_owner(owner, device, launch=True):
-    """Pack every live registered weight of flat buffer `owner` with one launch into persistent operand buffers and
-    stamp their cache entries.  The plan (buffers + device descriptor table) is rebuilt when the set of weights changes."""
+PACK_SPLIT = float(os.environ.get('HG_PACK_SPLIT', '0'))   # share of a buffer's weights in the first pack group (0: one group)
+
+
+def _pack_owner(owner, device, launch=True, record_on=None):
+    """Pack every live registered weight of flat buffer `owner` into persistent operand buffers (direct operands + squared
+    sums: hg_conv_pack_weights_multi; Winograd operands of the 3x3 weights: hg_wino_pack_weights_multi) and stamp their cache
+    entries.  With HG_PACK_SPLIT > 0 the weights go in TWO groups of launches, in registration (= forward) order: the
+    leading weights that together hold <= PACK_SPLIT of the bytes first (the discriminator's first five blocks are 5 % of
+    its weights: its forward pass could start behind a ~20 us pack while the bulk is packed beside it).  Measured at C3:
+    793.7 images/s with one group, 789.9 with the split (profiles/r05_ab_pack_split.json) -- no gain, the default is one group.  `record_on`: the stream the launches run on -- an event per group is recorded
+    there for the consumers (_await_pack).  The plan (buffers + device tables) is rebuilt when the set of weights changes."""
     live = []
     for key, (own, ref) in list(_cacheable.items()):
         p = ref()
@@ -305,44 +313,57 @@ def _pack_owner(owner, device, launch=True):
         if plan is None or plan['sig'] != sig:
             if torch.cuda.is_current_stream_capturing():
                 return False          # (the table upload is not capturable: per-weight launches for this capture)
-            items = (_PackItem * len(live))()
-            witems = []
-            bufs, blocks, wblocks = {}, 0, 0
-            for i, (key, p) in enumerate(live):
-                Co, Ci, k, _ = p.shape
-                wf = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_FWD), dtype=torch.float32, device=device)
-                wd = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_DGRAD), dtype=torch.float32, device=device)
-                # sum over the taps of W^2 (the demodulation coefficient's weight factor), from the same tile
-                wq = torch.empty((Co, Ci), dtype=torch.float32, device=device)
-                bufs[key] = (wf, wd, wq)
-                items[i] = _PackItem(p.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, blocks, wq.data_ptr())
-                blocks += lib.hg_conv_pack_blocks(Co, Ci)
-                wf.wino = wd.wino = False
-                if WINO and k == 3:        # the Winograd operands of the 3x3 weights (include/hg_wino.h), one more launch
-                    nf, nd = lib.hg_wino_packed_elems(Co, Ci, PACK_FWD), lib.hg_wino_packed_elems(Co, Ci, PACK_DGRAD)
-                    if nf:
-                        wf.wino = torch.empty(nf, dtype=torch.float32, device=device)
-                    if nd:
-                        wd.wino = torch.empty(nd, dtype=torch.float32, device=device)
-                    if nf or nd:
-                        witems.append(_WinoItem(p.data_ptr(), wf.wino.data_ptr() if nf else None,
-                                                wd.wino.data_ptr() if nd else None, Co, Ci, wblocks, 0))
-                        wblocks += lib.hg_wino_pack_blocks(Co, Ci, int(bool(nf)), int(bool(nd)))
-            raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8).clone()
-            plan = _multi[owner] = dict(sig=sig, bufs=bufs, table=raw.to(device), n=len(live), blocks=blocks, wn=len(witems),
-                                        wblocks=wblocks, wtable=None)
-            if witems:
-                arr = (_WinoItem * len(witems))(*witems)
-                plan['wtable'] = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(device)
+            total = sum(p.numel() for _, p in live)
+            ncut, run = 0, 0
+            for _, p in live:
+                if run + p.numel() > PACK_SPLIT * total:
+                    break
+                run += p.numel()
+                ncut += 1
+            cuts = [(0, ncut), (ncut, len(live))] if 0 < ncut < len(live) else [(0, len(live))]
+            bufs, groups = {}, []
+            for lo, hi in cuts:
+                items, witems, blocks, wblocks = [], [], 0, 0
+                for key, p in live[lo:hi]:
+                    Co, Ci, k, _ = p.shape
+                    wf = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_FWD), dtype=torch.float32, device=device)
+                    wd = torch.empty(lib.hg_conv_packed_elems(Co, Ci, k, PACK_DGRAD), dtype=torch.float32, device=device)
+                    # sum over the taps of W^2 (the demodulation coefficient's weight factor), from the same tile
+                    wq = torch.empty((Co, Ci), dtype=torch.float32, device=device)
+                    bufs[key] = (wf, wd, wq)
+                    items.append(_PackItem(p.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, blocks, wq.data_ptr()))
+                    blocks += lib.hg_conv_pack_blocks(Co, Ci)
+                    wf.wino = wd.wino = False
+                    if WINO and k == 3:        # the Winograd operands of the 3x3 weights (include/hg_wino.h), one more launch
+                        nf, nd = lib.hg_wino_packed_elems(Co, Ci, PACK_FWD), lib.hg_wino_packed_elems(Co, Ci, PACK_DGRAD)
+                        if nf:
+                            wf.wino = torch.empty(nf, dtype=torch.float32, device=device)
+                        if nd:
+                            wd.wino = torch.empty(nd, dtype=torch.float32, device=device)
+                        if nf or nd:
+                            witems.append(_WinoItem(p.data_ptr(), wf.wino.data_ptr() if nf else None,
+                                                    wd.wino.data_ptr() if nd else None, Co, Ci, wblocks, 0))
+                            wblocks += lib.hg_wino_pack_blocks(Co, Ci, int(bool(nf)), int(bool(nd)))
+                up = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(device)
+                groups.append(dict(keys={key for key, _ in live[lo:hi]}, table=up((_PackItem * len(items))(*items)), n=len(items),
+                                   blocks=blocks, wn=len(witems), wblocks=wblocks,
+                                   wtable=up((_WinoItem * len(witems))(*witems)) if witems else None))
+            plan = _multi[owner] = dict(sig=sig, bufs=bufs, groups=groups)
         if not launch:
             return True
         _await_pack(owner, device)         # an asynchronous pack of the same buffers still in flight goes first
-        check(lib.hg_conv_pack_weights_multi(plan['table'].data_ptr(), plan['n'], plan['blocks'], raw_stream(device)),
-              'hg_conv_pack_weights_multi')
-        if plan['wtable'] is not None:
-            check(lib.hg_wino_pack_weights_multi(plan['wtable'].data_ptr(), plan['wn'], plan['wblocks'], raw_stream(device)),
-                  'hg_wino_pack_weights_multi')
-        _pack_events.pop(owner, None)      # (prepack_async records the event of THIS launch right after)
+        _pack_events.pop(owner, None)
+        events = []
+        for g in plan['groups']:
+            check(lib.hg_conv_pack_weights_multi(g['table'].data_ptr(), g['n'], g['blocks'], raw_stream(device)),
+                  'hg_conv_pack_weights_multi')
+            if g['wtable'] is not None:
+                check(lib.hg_wino_pack_weights_multi(g['wtable'].data_ptr(), g['wn'], g['wblocks'], raw_stream(device)),
+                      'hg_wino_pack_weights_multi')
+            if record_on is not None:
+                events.append([record_on.record_event(), {record_on.cuda_stream}, g['keys']])
+        if events:
+            _pack_events[owner] = events
     for key, p in live:
         st = _stamp(p, owner)
         wf, wd, wq = plan['bufs'][key]
@@ -354,7 +375,7 @@ def _pack_owner(owner, device, launch=True):
 
 PREPACK = os.environ.get('HG_PREPACK', '1') != '0'
 _pack_streams = {}
-_pack_events = {}    # owner -> [event behind the asynchronous batched pack, ids of the streams that already wait for it]
+_pack_events = {}    # owner -> [[event behind a group of the asynchronous batched pack, ids of the streams that already wait for it, keys of the group]]
 
 
 def prepack_async(flat):
@@ -371,9 +392,7 @@ def prepack_async(flat):
         st = _pack_streams[device.index] = torch.cuda.Stream(device=device)
     st.wait_event(torch.cuda.current_stream(device).record_event())
     with torch.cuda.stream(st):
-        ok = _pack_owner(owner, device)
-        if ok:
-            _pack_events[owner] = [st.record_event(), {st.cuda_stream}]
+        ok = _pack_owner(owner, device, record_on=st)
     return ok
 
 
@@ -387,15 +406,18 @@ def drain_pack_streams():
     _pack_events.clear()
 
 
-def _await_pack(owner, device):
+def _await_pack(owner, device, key=None):
+    """The current stream waits for the asynchronous pack of flat buffer `owner` -- for the group that holds weight `key`
+    (None: every group) -- once per stream and event."""
     if torch.cuda.is_current_stream_capturing():    # (drain_pack_streams() ran before the capture began)
         return
-    ent = _pack_events.get(owner)
-    if ent is not None:
+    ents = _pack_events.get(owner)
+    if ents:
         cur = torch.cuda.current_stream(device)
-        if cur.cuda_stream not in ent[1]:
-            cur.wait_event(ent[0])
-            ent[1].add(cur.cuda_stream)
+        for ev, seen, keys in ents:
+            if (key is None or key in keys) and cur.cuda_stream not in seen:
+                cur.wait_event(ev)
+                seen.add(cur.cuda_stream)
 
 
 def pack_b6(w, mode):

@@ -59,6 +59,9 @@
 #ifndef HG_BWD_WAVES
 #define HG_BWD_WAVES 2  // min waves/SIMD the backward kernel is register-budgeted for
 #endif
+#if HG_BWD_WAVES > 2
+#error "HG_BWD_WAVES > 2: the shared-reciprocal assembly of k_hist_bwd clobbers v[240:255] (needs the 256-VGPR budget)"
+#endif
 
 #ifndef HG_HIST_PROBE
 #define HG_HIST_PROBE 0      // 1 (tagged experiment builds only): per-phase shader-cycle counters in k_hist_fwd / k_hist_bwd
@@ -2216,19 +2219,27 @@ DevParams make_dev(const hg_hist_params *p) {
 // The shared-reciprocal operand generation of k_hist_fwd forms products of four denominators 1 + t^2, |t| <= (13.9 +
 // max|boundary|) / sigma (log-chroma differences of clamped pixels lie in [-13.82, 13.82]): taken only when that product
 // stays below 1e30 (its reciprocal then is a normal float with room to spare).  HG_FWD_SHARE_RCP=0 switches it off (A/B).
+// (the kernels also evaluate the PADDED bins of a 32-wide tile, up to index 32 * ceil(h / 32) - 1 >= h - 1: the bound
+// takes the farthest padded bin centre lo + (padded - 1) * step, not only the boundary)
+static double share_rcp_tmax(const DevParams &d) {
+  const int padded = (d.h + 31) / 32 * 32;
+  const double far_hi = d.lo + (double)(padded - 1) * d.step;
+  double bmax = fabs(d.lo) > fabs(d.hi) ? fabs(d.lo) : fabs(d.hi);
+  bmax = fabs(far_hi) > bmax ? fabs(far_hi) : bmax;
+  return (13.9 + bmax) * d.inv_sigma_x;
+}
+
 bool fwd_share_rcp_ok(const DevParams &d) {
   static const bool enabled = [] { const char *e = getenv("HG_FWD_SHARE_RCP"); return !(e && e[0] == '0'); }();
   if (!enabled || d.proj != HG_PROJ_RGBUV) return false;
-  const double bmax = fabs(d.lo) > fabs(d.hi) ? fabs(d.lo) : fabs(d.hi);
-  const double tmax = (13.9 + bmax) * d.inv_sigma_x, den = 1.0 + tmax * tmax;
+  const double tmax = share_rcp_tmax(d), den = 1.0 + tmax * tmax;
   return den * den * den * den < 1e30;
 }
 
 bool bwd_share_rcp_ok(const DevParams &d) {      // the same product-of-four-denominators condition; HG_BWD_SHARE_RCP=0: A/B
   static const bool enabled = [] { const char *e = getenv("HG_BWD_SHARE_RCP"); return !(e && e[0] == '0'); }();
   if (!enabled) return false;
-  const double bmax = fabs(d.lo) > fabs(d.hi) ? fabs(d.lo) : fabs(d.hi);
-  const double tmax = (13.9 + bmax) * d.inv_sigma_x, den = 1.0 + tmax * tmax;
+  const double tmax = share_rcp_tmax(d), den = 1.0 + tmax * tmax;
   return den * den * den * den < 1e30;
 }
 

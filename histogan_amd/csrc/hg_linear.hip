@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_glin_bwd_params(const GArgs a) {
   }
 }
 
-int check_layers(const hg_glin_layer *layers, int n_layers, int B, int K, bool /*fwd*/, bool params) {
+int check_layers(const hg_glin_layer *layers, int n_layers, int B, int K, bool params) {
   if (!layers || n_layers <= 0 || n_layers > HG_GLIN_MAX || B <= 0 || K <= 0) return HG_EINVAL;
   if (B > 64 || (K & 31)) return HG_EUNSUPPORTED;
   for (int l = 0; l < n_layers; ++l) {
@@ -242,7 +242,7 @@ void fill_args(GArgs &a, const hg_glin_layer *layers, int n_layers, int B, int K
 extern "C" {
 
 int hg_grouped_linear_fwd(const hg_glin_layer *layers, int32_t n_layers, int32_t B, int32_t K, void *stream) {
-  const int rc = check_layers(layers, n_layers, B, K, true, false);
+  const int rc = check_layers(layers, n_layers, B, K, false);
   if (rc) return rc;
   GArgs a;
   fill_args(a, layers, n_layers, B, K, 32);
@@ -255,7 +255,7 @@ int hg_grouped_linear_fwd(const hg_glin_layer *layers, int32_t n_layers, int32_t
 }
 
 size_t hg_grouped_linear_bwd_input_workspace_bytes(const hg_glin_layer *layers, int32_t n_layers, int32_t B, int32_t K) {
-  if (check_layers(layers, n_layers, B, K, false, false)) return 0;
+  if (check_layers(layers, n_layers, B, K, false)) return 0;
   size_t chunks = 0;
   for (int l = 0; l < n_layers; ++l) chunks += (size_t)(layers[l].N + 127) / 128;
   return chunks * (size_t)B * K * sizeof(float);
@@ -263,7 +263,7 @@ size_t hg_grouped_linear_bwd_input_workspace_bytes(const hg_glin_layer *layers, 
 
 int hg_grouped_linear_bwd_input(const hg_glin_layer *layers, int32_t n_layers, float *const *gx, int32_t n_groups, int32_t B,
                                 int32_t K, void *workspace, size_t workspace_bytes, void *stream) {
-  const int rc = check_layers(layers, n_layers, B, K, false, false);
+  const int rc = check_layers(layers, n_layers, B, K, false);
   if (rc) return rc;
   if (!gx || n_groups != layers[n_layers - 1].group + 1 || !workspace) return HG_EINVAL;
   if (workspace_bytes < hg_grouped_linear_bwd_input_workspace_bytes(layers, n_layers, B, K)) return HG_EWORKSPACE;
@@ -291,7 +291,7 @@ int hg_grouped_linear_bwd_input(const hg_glin_layer *layers, int32_t n_layers, f
 }
 
 int hg_grouped_linear_bwd_params(const hg_glin_layer *layers, int32_t n_layers, int32_t B, int32_t K, void *stream) {
-  const int rc = check_layers(layers, n_layers, B, K, false, true);
+  const int rc = check_layers(layers, n_layers, B, K, true);
   if (rc) return rc;
   GArgs a;
   fill_args(a, layers, n_layers, B, K, 32);

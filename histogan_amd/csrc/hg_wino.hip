@@ -29,6 +29,24 @@
 #define HG_WINO_SPLIT_PHASE 0
 #endif
 
+// experiment knob (tagged builds only, results are garbage): bit 0 no patch loads, 1 no transform arithmetic, 2 no weight
+// loads, 3 no V stores, 4 no MFMAs, 5 no epilogue -- what each part of k_wino's loop costs (tools/wino_ablate.py)
+#ifndef HG_WINO_DBG
+#define HG_WINO_DBG 0
+#endif
+// 1: a patch row as ONE dword-aligned 16-byte load + two border selects; 0: dword + dwordx2 + dword with per-load zero fill
+#ifndef HG_WINO_ROWLOAD
+#define HG_WINO_ROWLOAD 1
+#endif
+// 1: the two waves of a SIMD alternate MFMA and transform halves (two barriers per chunk); 0: every wave in the same phase
+#ifndef HG_WINO_PINGPONG
+#define HG_WINO_PINGPONG 0
+#endif
+// 1: the phase's loads / transform spread between the MFMA steps (sched_group_barrier); 0: loads as a block in front
+#ifndef HG_WINO_SCHED
+#define HG_WINO_SCHED 0
+#endif
+
 namespace {
 
 constexpr unsigned kOOB = 0xFFFFFFFFu;
@@ -58,6 +76,7 @@ struct WinoArgs {
   int bt_x, bt_y;          // block tiles per map row / column
   int ksplit;
   float *slab;
+  int blocks, total_tiles;  // tiles per K split, tiles of the launch (= blocks * ksplit)
 };
 
 // accumulator row of register r (v_mfma_f32_32x32x2_f32: D[i][j], j = lane & 31, i = row(r, lane >> 5))
@@ -81,7 +100,13 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   // block -> (channel block, block tile); the channel block varies fastest: the blocks that read the same input tiles
   // are neighbours in dispatch order (their second read hits the Infinity Cache), and with >= 8 channel blocks every XCD
   // only ever sees an eighth of U
-  int pt = blockIdx.x;
+  // PERSISTENT: one workgroup per CU walks over the launch's tiles.  Every workgroup of a round reaches its epilogue at the
+  // same time (equal work, one workgroup per CU), so the outputs leave as chip-wide store bursts -- 5.6 us of a 27 us tile
+  // at 64 -> 64 channels (ablation, tools/wino_ablate.py); stores are fire-and-forget for the wave that issued them, so
+  // with the next tile started by the SAME workgroup they drain under its K loop instead of holding the CU.
+  for (int L = blockIdx.x; L < a.total_tiles; L += gridDim.x) {
+  int pt = L % a.blocks;
+  const int zs = L / a.blocks;
   const int nb = pt % a.nblk;
   pt /= a.nblk;
   const int bx = pt % a.bt_x;
@@ -93,25 +118,46 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
 
   // ---- this thread's patch: channel kc of the chunk, tile t of the block
   const int t = tid % TB, kc = tid / TB;
+  // One 16-byte load per patch row (4 instead of 12 loads per patch: the VMEM issue slots of a chunk, 16 per wave, were
+  // ~900 of its ~5400 cycles -- ablation).  The row starts at column 2 gtx - 1: dword-aligned only, which buffer loads
+  // accept; the range check is per instruction, so rows outside the image carry the offset 0xFFFFFFFF (hardware zero
+  // fill) while the left / right padding COLUMN of the border tiles arrives as a neighbour's value and is zeroed by a select.
+#if HG_WINO_ROWLOAD
+  unsigned vo[4];
+  bool c0bad = false, c3bad = false, sh1 = false;
+#else
   unsigned vo[4][3];
+#endif
   unsigned so = kOOB;
   {
     const int ttx = t & TWm, tty = (t >> a.lTW) & THm, timg = t >> (a.lTW + a.lTH);
     const int gtx = (bx << a.lTW) + ttx, gty = (by << a.lTH) + tty, b = b0 + timg;
     const bool ok = gtx < a.tiles_w && gty < a.tiles_h && b < a.B;
     const int x = 2 * gtx - 1, y0 = 2 * gty - 1;
+#if HG_WINO_ROWLOAD
+    c0bad = x < 0;
+    c3bad = x + 3 >= W;
+    // the one row whose first element would sit one element BEFORE the descriptor's base (image 0 / channel 0 of the chunk,
+    // input row 0, left border tile: offset -4 does not wrap into range) is loaded from column 0 and shifted by a select
+    sh1 = ok && timg == 0 && kc == 0 && gty == 0 && gtx == 0;
+#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int y = y0 + r;
       const bool rok = ok && (unsigned)y < (unsigned)H;
       const unsigned e = (unsigned)(((timg * K + kc) * H + y) * W + x);
+#if HG_WINO_ROWLOAD
+      vo[r] = rok ? (r == 1 && sh1 ? 0u : e * 4u) : kOOB;
+#else
       vo[r][0] = (rok && x >= 0) ? e * 4u : kOOB;
       vo[r][1] = rok ? (e + 1u) * 4u : kOOB;
       vo[r][2] = (rok && x + 3 < W) ? (e + 3u) * 4u : kOOB;
+#endif
     }
     if (FE && ok) so = (unsigned)(b * K + kc) * 4u;
   }
   const float *inblk = a.in + (size_t)b0 * K * HW;
+  [[maybe_unused]] const size_t in_elems = (size_t)a.B * K * HW;
   const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u);
   const __amdgpu_buffer_rsrc_t rs = make_rsrc(FE && a.iscale ? a.iscale : a.u);
   const bool has_is = FE && a.iscale != nullptr;
@@ -138,14 +184,31 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
 
   auto load_patch = [&](int c, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
+#if HG_WINO_ROWLOAD
+    // (the descriptor ends with the tensor: the last row's 16-byte load reaches one element past it)
+    const size_t rem = in_elems - ((size_t)b0 * K * HW + (size_t)c * KC * HW);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(inblk + (size_t)c * KC * HW, rem < (1ull << 30) ? (unsigned)rem * 4u : kOOB);
+#else
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(inblk + (size_t)c * KC * HW);
+#endif
+    if constexpr (HG_WINO_DBG & 1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) pd[S][e] = (float)(c + e);
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+#if HG_WINO_ROWLOAD
+      const f32x4 m = buf_load4(rx, vo[r], 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pd[S][4 * r + e] = m[e];
+#else
       pd[S][4 * r] = buf_load(rx, vo[r][0], 0);
       const f32x2 m = buf_load2(rx, vo[r][1], 0);
       pd[S][4 * r + 1] = m[0];
       pd[S][4 * r + 2] = m[1];
       pd[S][4 * r + 3] = buf_load(rx, vo[r][2], 0);
+#endif
     }
     if constexpr (FE) {
       if (has_is) ps[S] = buf_load(rs, so, c * KC * 4);
@@ -153,6 +216,13 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   };
   auto load_u = [&](int c, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
+    if constexpr (HG_WINO_DBG & 4) {
+#pragma unroll
+      for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+        for (int e = 0; e < NV; ++e) ua[S][x2][e] = (float)(c + e + x2);
+      return;
+    }
 #pragma unroll
     for (int x2 = 0; x2 < 2; ++x2) {
       if constexpr (NV >= 4) {
@@ -176,6 +246,31 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
     float d[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) d[e] = has_is ? pd[S][e] * ps[S] : pd[S][e];
+#if HG_WINO_ROWLOAD
+    {
+      const float m0 = d[4], m1 = d[5], m2 = d[6];
+      d[5] = sh1 ? m0 : m1;
+      d[6] = sh1 ? m1 : m2;
+      d[7] = sh1 ? m2 : d[7];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      d[4 * r] = c0bad ? 0.f : d[4 * r];
+      d[4 * r + 3] = c3bad ? 0.f : d[4 * r + 3];
+    }
+#endif
+    if constexpr (HG_WINO_DBG & 2) {
+      if constexpr (!(HG_WINO_DBG & 8)) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Vb[e * KC * TB] = d[e];
+      } else {
+        float acc_ = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_ += d[e];
+        if (acc_ == 12345.678f) Vb[0] = acc_;
+      }
+      return;
+    }
     float q[16];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -183,6 +278,14 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
       q[4 + c] = d[4 + c] + d[8 + c];
       q[8 + c] = d[8 + c] - d[4 + c];
       q[12 + c] = d[4 + c] - d[12 + c];
+    }
+    if constexpr (HG_WINO_DBG & 8) {
+      float acc_ = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc_ += (q[4 * r] - q[4 * r + 2]) + (q[4 * r + 1] + q[4 * r + 2]) + (q[4 * r + 2] - q[4 * r + 1]) * 3.f + (q[4 * r + 1] - q[4 * r + 3]) * 5.f;
+      if (acc_ == 12345.678f) Vb[0] = acc_;
+      return;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -195,23 +298,40 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   auto mfma_chunk = [&](int buf, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
     const float *Vc = smem + buf * VSZ + lk * TB + lm;
-    // all B operands of the chunk up front (16 registers): the MFMAs then run back to back
-    float bv[2][KC / 2][TP];
+    if constexpr (HG_WINO_DBG & 16) {
+      float t_ = 0.f;
 #pragma unroll
-    for (int x2 = 0; x2 < 2; ++x2)
+      for (int x2 = 0; x2 < 2; ++x2)
 #pragma unroll
-      for (int ks = 0; ks < KC / 2; ++ks)
+        for (int e = 0; e < NV; ++e) t_ += ua[S][x2][e];
+      acc[0][0][0][0] += t_ + Vc[0];
+      return;
+    }
+    // B operands one MFMA step ahead (two register slots), the order pinned: [reads of step s + 1][MFMAs of step s].  Left
+    // to itself the compiler issues a step's reads right in front of its MFMAs, behind an s_waitcnt: the wave then idles an
+    // LDS round trip per step, and the matrix pipe with it unless the SIMD's other wave happens to have MFMAs queued (a
+    // wave ALONE needed 3400 instead of 2048 cycles for a chunk's 32 MFMAs: the ping-pong experiment).
+    constexpr int NS = 2 * (KC / 2);
+    float bv[2][TP];
+    auto ldop = [&](int s_, int slot) __attribute__((always_inline)) {
+      const int x2 = s_ / (KC / 2), ks = s_ % (KC / 2);
 #pragma unroll
-        for (int j = 0; j < TP; ++j) bv[x2][ks][j] = Vc[((2 * wave + x2) * KC + 2 * ks) * TB + 32 * j];
+      for (int j = 0; j < TP; ++j) bv[slot][j] = Vc[((2 * wave + x2) * KC + 2 * ks) * TB + 32 * j];
+    };
+    ldop(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, (TP + 1) / 2, 0);
 #pragma unroll
-    for (int x2 = 0; x2 < 2; ++x2)
+    for (int s_ = 0; s_ < NS; ++s_) {
+      const int x2 = s_ / (KC / 2), ks = s_ % (KC / 2);
+      if (s_ + 1 < NS) ldop(s_ + 1, (s_ + 1) & 1);
 #pragma unroll
-      for (int ks = 0; ks < KC / 2; ++ks)
+      for (int i = 0; i < TC; ++i)
 #pragma unroll
-        for (int i = 0; i < TC; ++i)
-#pragma unroll
-          for (int j = 0; j < TP; ++j)
-            acc[x2][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[S][x2][ks * TC + i], bv[x2][ks][j], acc[x2][i][j], 0, 0, 0);
+        for (int j = 0; j < TP; ++j)
+          acc[x2][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[S][x2][ks * TC + i], bv[s_ & 1][j], acc[x2][i][j], 0, 0, 0);
+      if (s_ + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, (TP + 1) / 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TC * TP, 0);
+    }
   };
 
   // K chunks of this split, two phases per trip (V buffer / register sets 0, then 1).  Phase c: request the patch of chunk
@@ -223,13 +343,85 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   // outstanding load before the first MFMA of a chunk.  sched_barrier at the phase boundaries: the scheduler otherwise
   // hoists the first additions of the NEXT transform across the barrier, right behind the loads they consume.
   const int cps = (a.nch + a.ksplit - 1) / a.ksplit;
-  const int c_begin = blockIdx.z * cps;
+  const int c_begin = zs * cps;
   const int c_end = c_begin + cps < a.nch ? c_begin + cps : a.nch;
   const int nc = c_end - c_begin;
   typedef std::integral_constant<int, 0> S0;
   typedef std::integral_constant<int, 1> S1;
   auto clampc = [&](int c) __attribute__((always_inline)) { return c < c_end ? c : c_end - 1; };
 
+  // The order of a phase's instructions, one group per MFMA step (a B-operand read, its TC x TP MFMAs, then a share of the
+  // phase's global loads, transform arithmetic and V stores): the loads are requests for chunk c + 2 and can go anywhere in
+  // the phase -- issued as a block in front (12 per wave, 8 waves) they hold every wave of the CU at the head of the phase
+  // while the memory pipeline takes them in (ablation: 16 % of the kernel; tools/wino_ablate.py), spread between the MFMA
+  // groups they are absorbed while the matrix pipe drains its queue.
+  [[maybe_unused]] auto phase_schedule = [&]() __attribute__((always_inline)) {
+#if !HG_WINO_SPLIT_PHASE && HG_WINO_SCHED
+    constexpr int NG = 2 * (KC / 2);                           // MFMA steps per phase
+    constexpr int NLD = 12 + (NV >= 4 ? 2 * (NV / 4) : 2) + (FE ? 1 : 0);   // global loads per phase
+    constexpr int LPG = (NLD + NG - 1) / NG;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // DS read (one ds_read2 = the step's B operands)
+      __builtin_amdgcn_sched_group_barrier(0x008, TC * TP, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x020, LPG, 0);      // VMEM read
+      __builtin_amdgcn_sched_group_barrier(0x002, 48 / NG, 0);  // VALU (transform)
+      __builtin_amdgcn_sched_group_barrier(0x200, 8 / NG > 0 ? 8 / NG : 1, 0);   // DS write
+    }
+#endif
+  };
+
+#if HG_WINO_PINGPONG
+  // PING-PONG: the two waves that share a SIMD (wave w and w + 4: a workgroup's waves go to the SIMDs round robin) run the
+  // two halves of a chunk in opposite order, one barrier per half: while waves 0-3 multiply chunk c, waves 4-7 transform
+  // their patches of chunk c + 1 and issue their loads, then the roles swap.  With every wave in the same phase (the
+  // one-barrier loop) the transform / load / barrier time of a chunk ADDS to its MFMA time (ablation: 4096 + 900 + 600
+  // cycles per chunk) -- nothing is left on the SIMD to overlap it with; here the matrix pipe always has the other wave's
+  // MFMAs queued.  V(c + 1) is complete after both halves, i.e. before either group multiplies it; a V buffer is
+  // rewritten two halves after its last reader.  A transform frees its patch registers, so the patch of chunk c + 3 is
+  // requested right behind it (two chunks ahead), the weights of chunk c + 2 behind the MFMAs of chunk c.
+  // Both groups run the SAME instruction stream, group 1 half a chunk behind in MFMAs / ahead in transforms:
+  //   step     0    1    2    3    4    5
+  //   group 0  M0   T1   M1   T2   M2   T3 ..      (Mc = the MFMAs of chunk c, Tc = transform + store of the own patches
+  //   group 1  T1   M0   T2   M1   T3   M2 ..       of chunk c, then the request for the next patch into the freed registers)
+  // so only the chunk a transform works on and its V buffer differ (run-time scalars); the register sets are the same.
+  const int pgrp = __builtin_amdgcn_readfirstlane(wave >> 2);   // (scalar: it enters buffer descriptors and LDS bases)
+#define HG_WINO_HALF_BARRIER()          \
+  __builtin_amdgcn_sched_barrier(0);    \
+  __syncthreads();                      \
+  __builtin_amdgcn_sched_barrier(0)
+  if (nc > 0) {
+    load_patch(c_begin, S0{});
+    load_u(c_begin, S0{});
+    load_patch(clampc(c_begin + 1), S1{});
+    load_u(clampc(c_begin + 1), S1{});
+    transform_store(0, S0{});
+    load_patch(clampc(c_begin + 2 + pgrp), S0{});
+    HG_WINO_HALF_BARRIER();
+    if (pgrp) {                       // step 0 of group 1: T1
+      transform_store(1, S1{});
+      load_patch(clampc(c_begin + 2), S1{});
+      HG_WINO_HALF_BARRIER();
+    }
+    for (int c = c_begin; c + 1 < c_end; c += 2) {
+      mfma_chunk(0, S0{});
+      load_u(clampc(c + 2), S0{});
+      HG_WINO_HALF_BARRIER();
+      transform_store(pgrp ^ 1, S1{});
+      load_patch(clampc(c + 3 + pgrp), S1{});
+      HG_WINO_HALF_BARRIER();
+      mfma_chunk(1, S1{});
+      load_u(clampc(c + 3), S1{});
+      HG_WINO_HALF_BARRIER();
+      transform_store(pgrp, S0{});
+      load_patch(clampc(c + 4 + pgrp), S0{});
+      HG_WINO_HALF_BARRIER();
+    }
+    if (!pgrp) { HG_WINO_HALF_BARRIER(); }   // group 0 started a half earlier: the same number of barriers for every wave
+    if (nc & 1) mfma_chunk(0, S0{});
+  }
+#undef HG_WINO_HALF_BARRIER
+#else
   if (nc > 0) {
     load_patch(c_begin, S0{});
     load_u(c_begin, S0{});
@@ -241,24 +433,30 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
     __builtin_amdgcn_sched_barrier(0);
     for (int c = c_begin; c + 1 < c_end; c += 2) {
       load_patch(clampc(c + 2), S0{});
+#if HG_WINO_SPLIT_PHASE || !HG_WINO_SCHED
       __builtin_amdgcn_sched_barrier(0);   // (the loads stay in front: the scheduler would sink them behind the MFMAs)
+#endif
       mfma_chunk(0, S0{});
 #if HG_WINO_SPLIT_PHASE
       __builtin_amdgcn_sched_barrier(0);
 #endif
       transform_store(1, S1{});
       load_u(clampc(c + 2), S0{});
+      phase_schedule();
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
       load_patch(clampc(c + 3), S1{});
+#if HG_WINO_SPLIT_PHASE || !HG_WINO_SCHED
       __builtin_amdgcn_sched_barrier(0);
+#endif
       mfma_chunk(1, S1{});
 #if HG_WINO_SPLIT_PHASE
       __builtin_amdgcn_sched_barrier(0);
 #endif
       transform_store(0, S0{});
       load_u(clampc(c + 3), S1{});
+      phase_schedule();
       __builtin_amdgcn_sched_barrier(0);
       __syncthreads();
       __builtin_amdgcn_sched_barrier(0);
@@ -266,24 +464,77 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
     if (nc & 1) mfma_chunk(0, S0{});
   }
 
+#endif
+
   // ---- epilogue: one (channel tile, tile tile) pair at a time through LDS
+  if constexpr (HG_WINO_DBG & 32) {
+    float t_ = 0.f;
+#pragma unroll
+    for (int x2 = 0; x2 < 2; ++x2)
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t_ += acc[x2][i][j][r];
+    if (t_ == 12345.678f) a.out[tid] = t_;
+    __syncthreads();
+    continue;
+  }
   const bool fin = a.ksplit == 1;
-  float *ob = fin ? a.out : a.slab + (size_t)blockIdx.z * a.B * N * HW;
+  float *ob = fin ? a.out : a.slab + (size_t)zs * a.B * N * HW;
   const int erow = tid >> 5, ecol = tid & 31;
+  // Epilogue operands, requested BEFORE the first pass so that their latency runs under the LDS exchange (read where they
+  // are used, each pass waited for a global round trip of its own): per-channel bias / noise weight of this thread's 2 TC
+  // channels, demodulation scale per (channel, tile), the noise image rows of its TP tiles.
+  int etb[TP], ety[TP], etx[TP];
+  bool eok[TP];
+  float ebias[TC][2], enw[TC][2], eosc[TC][2][TP];
+  f32x2 enz[TP][2];
+#pragma unroll
+  for (int j = 0; j < TP; ++j) {
+    const int tl = 32 * j + ecol;
+    const int ttx = tl & TWm, tty = (tl >> a.lTW) & THm, timg = tl >> (a.lTW + a.lTH);
+    etx[j] = (bx << a.lTW) + ttx; ety[j] = (by << a.lTH) + tty; etb[j] = b0 + timg;
+    eok[j] = etx[j] < a.tiles_w && ety[j] < a.tiles_h && etb[j] < a.B;
+#pragma unroll
+    for (int p2 = 0; p2 < 2; ++p2) {
+      enz[j][p2] = f32x2{0.f, 0.f};
+      if (fin && a.noise_img && eok[j])
+        enz[j][p2] = *reinterpret_cast<const f32x2 *>(a.noise_img + ((size_t)etb[j] * a.noise_S + 2 * ety[j] + p2) * a.noise_S + 2 * etx[j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TC; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int n = n0 + 32 * i + erow + 16 * h, nc_ = n < N ? n : N - 1;
+      ebias[i][h] = (fin && a.bias) ? a.bias[nc_] : 0.f;
+      enw[i][h] = (fin && a.noise_img) ? a.noise_w[nc_] : 0.f;
+#pragma unroll
+      for (int j = 0; j < TP; ++j) eosc[i][h][j] = (fin && a.oscale && eok[j]) ? a.oscale[etb[j] * N + nc_] : 1.f;
+    }
 #pragma unroll
   for (int i = 0; i < TC; ++i) {
 #pragma unroll
     for (int j = 0; j < TP; ++j) {
+      // the residual addend of this pass (plain epilogue only), requested ahead of the exchange as well
+      f32x2 ead[2][2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+          ead[h][p2] = f32x2{0.f, 0.f};
+          const int n = n0 + 32 * i + erow + 16 * h;
+          if (fin && a.addend && eok[j] && n < N)
+            ead[h][p2] = *reinterpret_cast<const f32x2 *>(a.addend + (((size_t)etb[j] * N + n) * H + 2 * ety[j] + p2) * W + 2 * etx[j]);
+        }
       __syncthreads();   // (first pass: every wave is done with the V buffers this staging area aliases)
 #pragma unroll
       for (int x2 = 0; x2 < 2; ++x2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) smem[((2 * wave + x2) * 32 + mrow(r, lk)) * 32 + lm] = acc[x2][i][j][r];
       __syncthreads();
-      const int tl = 32 * j + ecol;
-      const int ttx = tl & TWm, tty = (tl >> a.lTW) & THm, timg = tl >> (a.lTW + a.lTH);
-      const int gtx = (bx << a.lTW) + ttx, gty = (by << a.lTH) + tty, b = b0 + timg;
-      const bool ok = gtx < a.tiles_w && gty < a.tiles_h && b < a.B;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int row = erow + 16 * h;
@@ -291,7 +542,7 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
         float m[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) m[e] = smem[(e * 32 + row) * 32 + ecol];
-        if (!ok || n >= N) continue;
+        if (!eok[j] || n >= N) continue;
         float s0[4], s1[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -303,29 +554,23 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
         y[0][1] = s0[1] - s0[2] - s0[3];
         y[1][0] = s1[0] + s1[1] + s1[2];
         y[1][1] = s1[1] - s1[2] - s1[3];
-        const size_t o = (((size_t)b * N + n) * H + 2 * gty) * W + 2 * gtx;
+        const size_t o = (((size_t)etb[j] * N + n) * H + 2 * ety[j]) * W + 2 * etx[j];
         if (fin) {
-          const float bias = a.bias ? a.bias[n] : 0.f;
-          const float osc = a.oscale ? a.oscale[b * N + n] : 1.f;
-          const float nw = a.noise_img ? a.noise_w[n] : 0.f;
 #pragma unroll
-          for (int p = 0; p < 2; ++p) {
-            f32x2 nz = {0.f, 0.f};
-            if (a.noise_img)
-              nz = *reinterpret_cast<const f32x2 *>(a.noise_img + ((size_t)b * a.noise_S + 2 * gty + p) * a.noise_S + 2 * gtx);
+          for (int p2 = 0; p2 < 2; ++p2)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-              float v = fmaf(y[p][q], osc, fmaf(nw, nz[q], bias));
-              if (a.addend) v += a.addend[o + p * W + q];
+              float v = fmaf(y[p2][q], eosc[i][h][j], fmaf(enw[i][h], enz[j][p2][q], ebias[i][h])) + ead[h][p2][q];
               if (a.slope > 0.f) v = v > 0.f ? v : a.slope * v;
-              y[p][q] = v;
+              y[p2][q] = v;
             }
-          }
         }
         *reinterpret_cast<f32x2 *>(ob + o) = f32x2{y[0][0], y[0][1]};
         *reinterpret_cast<f32x2 *>(ob + o + W) = f32x2{y[1][0], y[1][1]};
       }
     }
+  }
+  __syncthreads();   // the next tile's first transform writes the V buffer this staging area aliases
   }
 }
 
@@ -484,6 +729,7 @@ struct WinoWgArgs {
   int lPW, lPH, lPI;       // log2 of the chunk pattern: tiles per row, rows, images (PW * PH * PI == 8)
   int lcg, lrg;            // log2 of the column / row groups of a map (tiles_w >> lPW, tiles_h >> lPH)
   int Np, Kp;              // slab extents (multiples of 64)
+  int xtiles, total_blocks;  // (n, k) tiles, tiles x splits
 };
 
 constexpr int WG_P = 68;                   // LDS row pitch (floats) of a [position][tile] row of 64 channels
@@ -494,7 +740,9 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 31, lk = lane >> 5;
   const int H = a.H, W = a.W, K = a.K, N = a.N, HW = H * W;
-  const int k0 = (blockIdx.x % a.ktiles) * 64, n0 = (blockIdx.x / a.ktiles) * 64;
+  for (int L = blockIdx.x; L < a.total_blocks; L += gridDim.x) {    // persistent, as k_wino
+  const int bxy = L % a.xtiles, sp = L / a.xtiles;
+  const int k0 = (bxy % a.ktiles) * 64, n0 = (bxy / a.ktiles) * 64;
 
   // ---- transform role: tile t of the chunk pattern, channel ch of the block's 64 (input channel k0 + ch / gradient
   //      channel n0 + ch)
@@ -510,6 +758,17 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
   const unsigned m_tx0 = dtx == 0 ? kOOB : 0u, m_txl = dtx == PWm ? kOOB : 0u;
   const unsigned m_kbad = k0 + ch < K ? 0u : kOOB, m_nbad = n0 + ch < N ? 0u : kOOB;
   // patch element (r, c) relative to the chunk origin, against a base one row and one column BEFORE the image group
+#if HG_WINO_ROWLOAD
+  // one dword-aligned 16-byte load per patch row (as k_wino): the padding columns of border tiles arrive as neighbours'
+  // values and are cleared with the chunk's column masks when the patch is transformed; the one row that would begin
+  // one element before the tensor (image 0, channel 0, row 0, left border) is loaded from column 0 and shifted
+  unsigned vo[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) vo[r] = (unsigned)(((dimg * K + k0 + ch) * H + 2 * dty + r) * W + 2 * dtx) * 4u;
+  const unsigned m_first = (dimg == 0 && k0 + ch == 0 && dty == 0 && dtx == 0) ? kOOB : 0u;
+  const size_t in_elems = (size_t)a.B * K * HW;
+  unsigned cmask[2][3];      // [register set][left column, right column, shifted row 1]
+#else
   unsigned vo[4][3];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -518,6 +777,7 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
     vo[r][1] = (e + 1u) * 4u;
     vo[r][2] = (e + 3u) * 4u;
   }
+#endif
   const unsigned go = (unsigned)(((dimg * N + n0 + ch) * H + 2 * dty) * W + 2 * dtx) * 4u;
 
   f32x16 acc[2][2][2];
@@ -542,7 +802,6 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
     const unsigned left = cg == 0 ? kOOB : 0u, right = cg == ncg - 1 ? kOOB : 0u;
     const unsigned m_img = (unsigned)((a.B - 1 - b0 - dimg) >> 31);                       // all ones when b0 + dimg >= B
     const unsigned soff = (unsigned)(((rg << a.lPH) * 2) * W + (cg << a.lPW) * 2) * 4u;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.in + (size_t)b0 * K * HW - (W + 1));
     const __amdgpu_buffer_rsrc_t rg_ = make_rsrc(a.gout + (size_t)b0 * N * HW);
     const unsigned base = m_kbad | m_img;
     const unsigned c0 = left & m_tx0, c3 = right & m_txl;
@@ -550,6 +809,20 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
     rm[0] = base | (top & m_row0);
     rm[1] = rm[2] = base;
     rm[3] = base | (bot & m_rowl);
+#if HG_WINO_ROWLOAD
+    // (the descriptor ends with the tensor: the last row's 16-byte load reaches one element past it)
+    const size_t rem = in_elems - (size_t)b0 * K * HW + (size_t)(W + 1);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.in + (size_t)b0 * K * HW - (W + 1), rem < (1ull << 30) ? (unsigned)rem * 4u : kOOB);
+    const unsigned shm = (b0 == 0 && rg == 0 && cg == 0) ? m_first : 0u;
+    cmask[S][0] = c0; cmask[S][1] = c3; cmask[S][2] = shm;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 m = buf_load4(rx, (vo[r] + (r == 1 ? (shm & 4u) : 0u)) | rm[r], (int)soff);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pd[S][4 * r + e] = m[e];
+    }
+#else
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.in + (size_t)b0 * K * HW - (W + 1));
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       pd[S][4 * r] = buf_load(rx, vo[r][0] | rm[r] | c0, (int)soff);
@@ -558,6 +831,7 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
       pd[S][4 * r + 2] = m[1];
       pd[S][4 * r + 3] = buf_load(rx, vo[r][2] | rm[r] | c3, (int)soff);
     }
+#endif
     const unsigned gm = m_nbad | m_img;
     const f32x2 g0 = buf_load2(rg_, go | gm, (int)soff);
     const f32x2 g1 = buf_load2(rg_, (go + (unsigned)W * 4u) | gm, (int)soff);
@@ -568,13 +842,30 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
     float *Mb = smem + buf * 2 * WG_OP + t * WG_P + ch;   // dM [position][tile][n]
     float *Vb = Mb + WG_OP;                               // V  [position][tile][k]
     // V = B^T d B
+    float d[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) d[e] = pd[S][e];
+#if HG_WINO_ROWLOAD
+    {
+      const bool sh = cmask[S][2] != 0u;
+      const float m0 = d[4], m1 = d[5], m2 = d[6];
+      d[5] = sh ? m0 : m1;
+      d[6] = sh ? m1 : m2;
+      d[7] = sh ? m2 : d[7];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        d[4 * r] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, d[4 * r]) & ~cmask[S][0]);
+        d[4 * r + 3] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, d[4 * r + 3]) & ~cmask[S][1]);
+      }
+    }
+#endif
     float q[16];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      q[0 + c] = pd[S][0 + c] - pd[S][8 + c];
-      q[4 + c] = pd[S][4 + c] + pd[S][8 + c];
-      q[8 + c] = pd[S][8 + c] - pd[S][4 + c];
-      q[12 + c] = pd[S][4 + c] - pd[S][12 + c];
+      q[0 + c] = d[0 + c] - d[8 + c];
+      q[4 + c] = d[4 + c] + d[8 + c];
+      q[8 + c] = d[8 + c] - d[4 + c];
+      q[12 + c] = d[4 + c] - d[12 + c];
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -619,7 +910,6 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
 
   // this block's chunks: a contiguous range (consecutive chunks continue along the tile row: the other half of the cache
   // lines just fetched); two per trip, loads unconditional with a clamped index, as k_wino
-  const int sp = blockIdx.y;
   const int cps = (a.nchunks + a.splits - 1) / a.splits;
   const int c0 = sp * cps;
   const int nc = c0 < a.nchunks ? (c0 + cps <= a.nchunks ? cps : a.nchunks - c0) : 0;
@@ -662,6 +952,8 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           sb[((size_t)(2 * wave + x2) * a.Np + n0 + 32 * i + mrow(r, lk)) * a.Kp + k0 + 32 * j + lm] = acc[x2][i][j][r];
+  __syncthreads();   // (the next tile's first transform writes the LDS buffers the slowest wave may still read)
+  }
 }
 
 // gw[n][k][3][3] = G^T (sum_s slab[s][.][n][k]) G.  Block = (n, 4 * KQ consecutive k), KQ = 256 / SG: thread (kq = 4 k's,
@@ -831,7 +1123,10 @@ int launch_wino(const WinoArgs &a, const WinoPlan &p, bool fe, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr[fe] = true;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)p.blocks, 1, (unsigned)p.ksplit), dim3(512), lds, st, a);
+  const long long total = p.blocks * a.ksplit;
+  static const int persist = getenv("HG_WINO_PERSIST") ? atoi(getenv("HG_WINO_PERSIST")) : 1;
+  const long long grid = persist && total > num_cus() ? num_cus() : total;   // (512 threads, ~215 registers: one per CU)
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(512), lds, st, a);
   HG_LAUNCH_CHECK();
   return HG_OK;
 }
@@ -905,6 +1200,7 @@ int hg_wino_conv2d(const float *in, const float *u, float *out, const float *isc
   a.nblk = p.nblk; a.nch = p.nch; a.lTW = p.lTW; a.lTH = p.lTH; a.lNI = p.lNI;
   a.tiles_w = p.tiles_w; a.tiles_h = p.tiles_h; a.bt_x = p.bt_x; a.bt_y = p.bt_y;
   a.ksplit = p.ksplit; a.slab = (float *)workspace;
+  a.blocks = (int)p.blocks; a.total_tiles = (int)(p.blocks * p.ksplit);
   hipStream_t st = (hipStream_t)stream;
   const bool fe = iscale != nullptr;
   int rc = p.variant == 0 ? launch_wino<2, 2, 8>(a, p, fe, st) : launch_wino<1, 4, 4>(a, p, fe, st);
@@ -958,7 +1254,10 @@ int hg_wino_wgrad(const float *in, const float *gout, float *gw, int32_t B, int3
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL(k_wino_wgrad, dim3((unsigned)(p.ktiles * p.ntiles), (unsigned)p.splits), dim3(512), lds, st, a);
+  a.xtiles = p.ktiles * p.ntiles; a.total_blocks = a.xtiles * p.splits;
+  static const int persist = getenv("HG_WINO_PERSIST") ? atoi(getenv("HG_WINO_PERSIST")) : 1;
+  const int grid = persist && a.total_blocks > num_cus() ? num_cus() : a.total_blocks;
+  hipLaunchKernelGGL(k_wino_wgrad, dim3((unsigned)grid), dim3(512), lds, st, a);
   HG_LAUNCH_CHECK();
   if (p.splits >= 16)
     hipLaunchKernelGGL(k_wino_wgrad_reduce<32>, dim3((unsigned)((a.Kp + 31) / 32), (unsigned)N), dim3(256), 0, st, a.slab, gw, N, K,

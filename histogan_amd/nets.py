@@ -10,7 +10,7 @@ execution plan:
 * GeneratorBlock (reference :443-502) fuses the bilinear x2 upsample into conv1's prologue and the
   noise add + LeakyReLU(0.2) (+ demodulation) into each conv's epilogue.
 * Discriminator (reference :505-631): every convolution (3x3, 1x1, 3x3 stride 2) runs on the same MFMA
-  implicit-GEMM kernels through autograd Functions that are differentiable to any order (the gradient
+  implicit-GEMM kernels through autograd Functions that are differentiable to any order (convolutions; the grouped style projections, the fused generator stage and the modulation / epilogue kernels are first order: ops.py) (the gradient
   penalty, reference :156-163, needs the second); LeakyReLU / residual add / Linear stay torch ops.
 """
 import os
@@ -204,7 +204,8 @@ class Generator(nn.Module):
         _noise_t(input_noise)
         rgb = None
         layers = [m for block in self.blocks for m in (block.to_style1, block.to_style2, block.to_rgb.to_style)]
-        if styles.dtype == torch.float32 and ops.grouped_linear_supported([styles[0]], [m.weight for m in layers]):
+        if (styles.dtype == torch.float32 and styles.shape[0] >= len(self.blocks)     # (fewer style rows than blocks: the zip below)
+                and ops.grouped_linear_supported([styles[0]], [m.weight for m in layers])):
             # The 21 style projections (three nn.Linear(512, C) per block on the block's style vector) as ONE launch
             # (include/hg_linear.h) instead of 21 library GEMMs of 32 ... 64 workgroups -- and 3 launches instead of 42 GEMMs +
             # 21 bias reductions + the gradient sums in the backward.  Without autograd they still run beside the head of the

@@ -378,7 +378,11 @@ def grouped_linear_supported(xs, ws):
 
 
 class _GroupedLinear(torch.autograd.Function):
-    """y_l = x_g(l) @ W_l^T + b_l for a list of nn.Linear layers whose inputs come in groups (histoGAN/histoGAN.py:372, 450,
+    """FIRST-ORDER ONLY (once_differentiable backward): a double backward through the generator's style projections
+    (create_graph=True through G) raises -- set HG_GROUPED_STYLES=0 for such uses (one F.linear per projection,
+    differentiable to any order); the trainer's path-length term is a finite difference and its gradient penalty is D-only.
+
+    y_l = x_g(l) @ W_l^T + b_l for a list of nn.Linear layers whose inputs come in groups (histoGAN/histoGAN.py:372, 450,
     454: to_style1 / to_style2 / to_rgb.to_style of one generator block share the block's style vector).  ONE launch
     forward (hg_grouped_linear_fwd), three backward (input gradients: two, parameter gradients: one)."""
 

@@ -9,7 +9,8 @@
  * wavefront on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation in k order).
  *
  * Conventions as in hg_hist.h: return 0 / negative HG_E* / positive hipError_t; device pointers; fp32; row-major contiguous;
- * enqueue on `stream`; never allocate or synchronise.  Limits: batch <= 64, in_features % 16 == 0, <= HG_GLIN_MAX layers.
+ * enqueue on `stream`; never allocate or synchronise.  Limits: batch <= 64, in_features % 32 == 0,
+ * out_features % 4 == 0 per layer, x / w / y 16-byte aligned, <= HG_GLIN_MAX layers (anything else: HG_EUNSUPPORTED).
  */
 #ifndef HG_LINEAR_H
 #define HG_LINEAR_H

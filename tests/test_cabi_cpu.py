@@ -201,3 +201,32 @@ def test_grouped_linear_argument_validation(L):
     bad = tab((64, 0)); bad[0].w = 0x2004
     assert L.lib.hg_grouped_linear_fwd(bad, 1, 32, 512, None) == -1        # misaligned
     assert ctypes.sizeof(T) == 56
+
+
+def test_wino_host_logic(L):
+    """include/hg_wino.h, host side only (no launch): operand sizes / pack blocks of both channel-block variants, which
+    shapes are served, workspace queries, argument validation."""
+    lib = L.lib
+    # 64-channel blocks, 8-channel chunks: 16 positions x blocks x chunks x 512 floats
+    assert lib.hg_wino_packed_elems(128, 256, 0) == 16 * 2 * 32 * 512
+    assert lib.hg_wino_packed_elems(128, 256, 1) == 16 * 4 * 16 * 512          # data gradient: K = Co, N = Ci
+    # 32-channel variant (N <= 32): 4-channel chunks, 128 floats per (position, block, chunk)
+    assert lib.hg_wino_packed_elems(32, 64, 0) == 16 * 1 * 16 * 128
+    assert lib.hg_wino_packed_elems(64, 36, 0) == 0 and lib.hg_wino_packed_elems(0, 8, 0) == 0 and lib.hg_wino_packed_elems(8, 8, 2) == 0
+    assert lib.hg_wino_pack_blocks(128, 256, 1, 1) == 2 * 32 + 4 * 16
+    assert lib.hg_wino_pack_blocks(32, 64, 1, 0) == 4 * 1                      # variant 1: four chunks per 512-thread block
+    # served shapes (256 CUs assumed without a GPU)
+    assert lib.hg_wino_supported(32, 256, 128, 64, 64) == 1 and lib.hg_wino_supported(64, 1024, 2048, 2, 2) == 1
+    assert lib.hg_wino_supported(32, 256, 128, 64, 63) == 0 and lib.hg_wino_supported(32, 16, 32, 128, 128) == 0
+    assert lib.hg_wino_supported(32, 32, 32, 256, 256) == 0 and lib.hg_wino_supported(32, 64, 32, 256, 256) == 1
+    assert lib.hg_wino_wgrad_supported(32, 256, 128, 64, 64) == 1 and lib.hg_wino_wgrad_supported(32, 2048, 2048, 4, 4) == 1
+    assert lib.hg_wino_wgrad_supported(64, 1024, 2048, 2, 2) == 0 and lib.hg_wino_wgrad_supported(32, 32, 64, 64, 64) == 0
+    # a launch that cannot fill the chip with output tiles splits K into slabs; a full one needs no scratch
+    assert lib.hg_wino_workspace_bytes(32, 256, 128, 64, 64) == 0
+    assert lib.hg_wino_workspace_bytes(32, 2048, 1024, 8, 8) % (32 * 1024 * 64 * 4) == 0 and lib.hg_wino_workspace_bytes(32, 2048, 1024, 8, 8) > 0
+    assert lib.hg_wino_wgrad_workspace_bytes(32, 256, 128, 64, 64) == 32 * 16 * 128 * 256 * 4     # 8 (n, k) tiles -> 32 splits
+    assert lib.hg_wino_wgrad_workspace_bytes(32, 64, 64, 24, 24) == 0
+    # NULL pointers / bad epilogue combinations are rejected before any launch
+    assert lib.hg_wino_conv2d(None, None, None, None, None, None, None, None, 0, 0.0, None, 1, 8, 8, 4, 4, None, 0, None) < 0
+    assert lib.hg_wino_wgrad(None, None, None, 1, 8, 8, 4, 4, None, 0, None) < 0
+    assert lib.hg_wino_pack_weights(None, None, 8, 8, 0, None) < 0

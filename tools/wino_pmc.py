@@ -9,13 +9,37 @@ from histogan_amd import conv as C
 dev = torch.device('cuda:0')
 B = 32
 it = int(os.environ.get('HG_ONE_ITERS', 4))
-for K, N, S in ((256, 128, 64), (512, 512, 16)):
+ONLY = os.environ.get('HG_PMC_ONLY', '')      # 'roofline': bench.py's roofline launch alone (per-launch FETCH_SIZE / WRITE_SIZE)
+FWD = ((256, 128, 64),) if ONLY == 'roofline' else ((256, 128, 64), (512, 512, 16))
+WG = ((256, 128, 64),) if ONLY == 'roofline' else ((512, 512, 16), (128, 128, 64))
+if ONLY == 'leading':
+    # bench.py's `leading_kernels` launches, one kernel-trace line each: the data gradient at 512 -> 256 @32^2 and the
+    # no-autograd generator stage (modulate + conv + demodulate + noise + LeakyReLU in one hg_wino_conv2d) at 256 -> 128 @64^2
+    from histogan_amd import ops
+    K, N, S = 512, 256, 32
+    w = torch.randn(N, K, 3, 3, device=dev) / (K * 9) ** 0.5
+    go = torch.randn(B, N, S, S, device=dev)
+    ud = C._wino_pack(w, C.PACK_DGRAD)
+    for _ in range(it):
+        C.wino_conv(go, ud, K)
+    K, N, S = 256, 128, 64
+    with torch.no_grad():
+        x = torch.randn(B, K, S, S, device=dev)
+        st = 0.3 * torch.randn(B, K, device=dev)
+        w = torch.randn(N, K, 3, 3, device=dev) / (K * 9) ** 0.5
+        nzt = torch.rand(B, 256, 256, device=dev)
+        wn, bn = torch.randn(N, device=dev), torch.randn(N, device=dev)
+        for _ in range(it):
+            ops.modconv_stage(x, st, w, nzt, wn, bn, demod=True, upsample=False, act=True)
+    torch.cuda.synchronize()
+    sys.exit(0)
+for K, N, S in FWD:
     x = torch.randn(B, K, S, S, device=dev)
     w = torch.randn(N, K, 3, 3, device=dev) / (K * 9) ** 0.5
     u = C._wino_pack(w, C.PACK_FWD)
     for _ in range(it):
         C.wino_conv(x, u, N)
-for K, N, S in ((512, 512, 16), (128, 128, 64)):
+for K, N, S in WG:
     x = torch.randn(B, K, S, S, device=dev)
     go = torch.randn(B, N, S, S, device=dev)
     assert C.wino_wgrad_supported(B, K, N, S, S)
