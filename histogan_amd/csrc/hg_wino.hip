@@ -24,29 +24,6 @@
 #include "../../include/hg_conv.h"
 #include "../../include/hg_wino.h"
 
-// experiment knob: 1 = MFMAs and the next chunk's transform as separate scheduling regions (no interleaving)
-#ifndef HG_WINO_SPLIT_PHASE
-#define HG_WINO_SPLIT_PHASE 0
-#endif
-
-// experiment knob (tagged builds only, results are garbage): bit 0 no patch loads, 1 no transform arithmetic, 2 no weight
-// loads, 3 no V stores, 4 no MFMAs, 5 no epilogue -- what each part of k_wino's loop costs (tools/wino_ablate.py)
-#ifndef HG_WINO_DBG
-#define HG_WINO_DBG 0
-#endif
-// 1: a patch row as ONE dword-aligned 16-byte load + two border selects; 0: dword + dwordx2 + dword with per-load zero fill
-#ifndef HG_WINO_ROWLOAD
-#define HG_WINO_ROWLOAD 1
-#endif
-// 1: the two waves of a SIMD alternate MFMA and transform halves (two barriers per chunk); 0: every wave in the same phase
-#ifndef HG_WINO_PINGPONG
-#define HG_WINO_PINGPONG 0
-#endif
-// 1: the phase's loads / transform spread between the MFMA steps (sched_group_barrier); 0: loads as a block in front
-#ifndef HG_WINO_SCHED
-#define HG_WINO_SCHED 0
-#endif
-
 namespace {
 
 constexpr unsigned kOOB = 0xFFFFFFFFu;
@@ -92,123 +69,82 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   static_assert(NV == 2 || NV % 4 == 0, "operand loads are 8 or 16 bytes");
   constexpr int VSZ = 16 * KC * TB;      // floats of one V buffer (32 KB)
   extern __shared__ float smem[];        // [2][16][KC][TB]; the epilogue reuses it as [16][32][32]
+  typedef std::integral_constant<int, 0> S0;
+  typedef std::integral_constant<int, 1> S1;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 31, lk = lane >> 5;
   const int H = a.H, W = a.W, K = a.K, N = a.N, HW = H * W;
-
-  // block -> (channel block, block tile); the channel block varies fastest: the blocks that read the same input tiles
-  // are neighbours in dispatch order (their second read hits the Infinity Cache), and with >= 8 channel blocks every XCD
-  // only ever sees an eighth of U
-  // PERSISTENT: one workgroup per CU walks over the launch's tiles.  Every workgroup of a round reaches its epilogue at the
-  // same time (equal work, one workgroup per CU), so the outputs leave as chip-wide store bursts -- 5.6 us of a 27 us tile
-  // at 64 -> 64 channels (ablation, tools/wino_ablate.py); stores are fire-and-forget for the wave that issued them, so
-  // with the next tile started by the SAME workgroup they drain under its K loop instead of holding the CU.
-  for (int L = blockIdx.x; L < a.total_tiles; L += gridDim.x) {
-  int pt = L % a.blocks;
-  const int zs = L / a.blocks;
-  const int nb = pt % a.nblk;
-  pt /= a.nblk;
-  const int bx = pt % a.bt_x;
-  pt /= a.bt_x;
-  const int by = pt % a.bt_y;
-  const int grp = pt / a.bt_y;
-  const int n0 = nb * NB, b0 = grp << a.lNI;
   const int TWm = (1 << a.lTW) - 1, THm = (1 << a.lTH) - 1;
+  const int t = tid % TB, kc = tid / TB;               // this thread's patch: channel kc of the chunk, tile t of the block
+  const size_t in_elems = (size_t)a.B * K * HW;
+  const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u);
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(FE && a.iscale ? a.iscale : a.u);
+  const bool has_is = FE && a.iscale != nullptr;
+  const int cps = (a.nch + a.ksplit - 1) / a.ksplit;   // K chunks per split
 
-  // ---- this thread's patch: channel kc of the chunk, tile t of the block
-  const int t = tid % TB, kc = tid / TB;
-  // One 16-byte load per patch row (4 instead of 12 loads per patch: the VMEM issue slots of a chunk, 16 per wave, were
-  // ~900 of its ~5400 cycles -- ablation).  The row starts at column 2 gtx - 1: dword-aligned only, which buffer loads
-  // accept; the range check is per instruction, so rows outside the image carry the offset 0xFFFFFFFF (hardware zero
-  // fill) while the left / right padding COLUMN of the border tiles arrives as a neighbour's value and is zeroed by a select.
-#if HG_WINO_ROWLOAD
-  unsigned vo[4];
+  // ---- state of the tile in work (tile_setup): where it is, and this thread's patch of it.
+  // One 16-byte load per patch row (4 instead of 12 loads per patch: a chunk's 16 VMEM issue slots per wave were ~900 of its
+  // ~5400 cycles -- ablation, profiles/r05_wino_ablation.txt).  The row starts at column 2 gtx - 1: dword-aligned only,
+  // which buffer loads accept; the range check is per instruction, so rows outside the image carry the offset 0xFFFFFFFF
+  // (hardware zero fill) while the left / right padding COLUMN of a border tile arrives as a neighbour's value and is zeroed
+  // by a select; the one row that would begin an element BEFORE the descriptor's base (image 0 / channel 0 of the chunk, input
+  // row 0, left border: offset -4 does not wrap into range) is loaded from column 0 and shifted by a select; the descriptor
+  // ends with the tensor (the last row's load reaches one element past it).
+  int nb = 0, bx = 0, by = 0, b0 = 0, zs = 0, c_begin = 0, c_end = 0;
+  const float *inblk = a.in;
+  unsigned vo[4], so = kOOB, uo[2];
   bool c0bad = false, c3bad = false, sh1 = false;
-#else
-  unsigned vo[4][3];
-#endif
-  unsigned so = kOOB;
-  {
+  // tile -> (K split, block tile, channel block); the channel block varies fastest: the workgroups that read the same
+  // input tiles are neighbours in dispatch order (their second read hits the Infinity Cache), and with >= 8 channel blocks
+  // every XCD only ever sees an eighth of U
+  auto tile_setup = [&](int L) __attribute__((always_inline)) {
+    int pt = L % a.blocks;
+    zs = L / a.blocks;
+    nb = pt % a.nblk;
+    pt /= a.nblk;
+    bx = pt % a.bt_x;
+    pt /= a.bt_x;
+    by = pt % a.bt_y;
+    b0 = (pt / a.bt_y) << a.lNI;
+    c_begin = zs * cps;
+    c_end = c_begin + cps < a.nch ? c_begin + cps : a.nch;
+    inblk = a.in + (size_t)b0 * K * HW;
     const int ttx = t & TWm, tty = (t >> a.lTW) & THm, timg = t >> (a.lTW + a.lTH);
     const int gtx = (bx << a.lTW) + ttx, gty = (by << a.lTH) + tty, b = b0 + timg;
     const bool ok = gtx < a.tiles_w && gty < a.tiles_h && b < a.B;
     const int x = 2 * gtx - 1, y0 = 2 * gty - 1;
-#if HG_WINO_ROWLOAD
     c0bad = x < 0;
     c3bad = x + 3 >= W;
-    // the one row whose first element would sit one element BEFORE the descriptor's base (image 0 / channel 0 of the chunk,
-    // input row 0, left border tile: offset -4 does not wrap into range) is loaded from column 0 and shifted by a select
     sh1 = ok && timg == 0 && kc == 0 && gty == 0 && gtx == 0;
-#endif
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int y = y0 + r;
       const bool rok = ok && (unsigned)y < (unsigned)H;
       const unsigned e = (unsigned)(((timg * K + kc) * H + y) * W + x);
-#if HG_WINO_ROWLOAD
       vo[r] = rok ? (r == 1 && sh1 ? 0u : e * 4u) : kOOB;
-#else
-      vo[r][0] = (rok && x >= 0) ? e * 4u : kOOB;
-      vo[r][1] = rok ? (e + 1u) * 4u : kOOB;
-      vo[r][2] = (rok && x + 3 < W) ? (e + 3u) * 4u : kOOB;
-#endif
     }
-    if (FE && ok) so = (unsigned)(b * K + kc) * 4u;
-  }
-  const float *inblk = a.in + (size_t)b0 * K * HW;
-  [[maybe_unused]] const size_t in_elems = (size_t)a.B * K * HW;
-  const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.u);
-  const __amdgpu_buffer_rsrc_t rs = make_rsrc(FE && a.iscale ? a.iscale : a.u);
-  const bool has_is = FE && a.iscale != nullptr;
-
-  // this wave's operand slices of U: position xi = 2 wave + x2
-  unsigned uo[2];
+    so = (FE && ok) ? (unsigned)(b * K + kc) * 4u : kOOB;
+    // this wave's operand slices of U: position xi = 2 wave + x2
 #pragma unroll
-  for (int x2 = 0; x2 < 2; ++x2)
-    uo[x2] = (unsigned)((((2 * wave + x2) * a.nblk + nb) * a.nch) * (NV * 64) + lane * (NV >= 4 ? 4 : 2)) * 4u;
+    for (int x2 = 0; x2 < 2; ++x2)
+      uo[x2] = (unsigned)((((2 * wave + x2) * a.nblk + nb) * a.nch) * (NV * 64) + lane * (NV >= 4 ? 4 : 2)) * 4u;
+  };
 
   f32x16 acc[2][TC][TP];
-#pragma unroll
-  for (int x2 = 0; x2 < 2; ++x2)
-#pragma unroll
-    for (int i = 0; i < TC; ++i)
-#pragma unroll
-      for (int j = 0; j < TP; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[x2][i][j][r] = 0.f;
-
-  float pd[2][16];      // [register set][patch element]: the patch of chunk c lives in set c & 1
+  float pd[2][16];      // [register set][patch element]: the patch of chunk c lives in set (c - c_begin) & 1
   float ps[2] = {1.f, 1.f};
   float ua[2][2][NV];   // [register set][position][operand]
 
   auto load_patch = [&](int c, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-#if HG_WINO_ROWLOAD
-    // (the descriptor ends with the tensor: the last row's 16-byte load reaches one element past it)
     const size_t rem = in_elems - ((size_t)b0 * K * HW + (size_t)c * KC * HW);
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(inblk + (size_t)c * KC * HW, rem < (1ull << 30) ? (unsigned)rem * 4u : kOOB);
-#else
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(inblk + (size_t)c * KC * HW);
-#endif
-    if constexpr (HG_WINO_DBG & 1) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) pd[S][e] = (float)(c + e);
-      return;
-    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-#if HG_WINO_ROWLOAD
       const f32x4 m = buf_load4(rx, vo[r], 0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) pd[S][4 * r + e] = m[e];
-#else
-      pd[S][4 * r] = buf_load(rx, vo[r][0], 0);
-      const f32x2 m = buf_load2(rx, vo[r][1], 0);
-      pd[S][4 * r + 1] = m[0];
-      pd[S][4 * r + 2] = m[1];
-      pd[S][4 * r + 3] = buf_load(rx, vo[r][2], 0);
-#endif
     }
     if constexpr (FE) {
       if (has_is) ps[S] = buf_load(rs, so, c * KC * 4);
@@ -216,13 +152,6 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   };
   auto load_u = [&](int c, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    if constexpr (HG_WINO_DBG & 4) {
-#pragma unroll
-      for (int x2 = 0; x2 < 2; ++x2)
-#pragma unroll
-        for (int e = 0; e < NV; ++e) ua[S][x2][e] = (float)(c + e + x2);
-      return;
-    }
 #pragma unroll
     for (int x2 = 0; x2 < 2; ++x2) {
       if constexpr (NV >= 4) {
@@ -246,7 +175,6 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
     float d[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) d[e] = has_is ? pd[S][e] * ps[S] : pd[S][e];
-#if HG_WINO_ROWLOAD
     {
       const float m0 = d[4], m1 = d[5], m2 = d[6];
       d[5] = sh1 ? m0 : m1;
@@ -258,19 +186,6 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
       d[4 * r] = c0bad ? 0.f : d[4 * r];
       d[4 * r + 3] = c3bad ? 0.f : d[4 * r + 3];
     }
-#endif
-    if constexpr (HG_WINO_DBG & 2) {
-      if constexpr (!(HG_WINO_DBG & 8)) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) Vb[e * KC * TB] = d[e];
-      } else {
-        float acc_ = 0.f;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc_ += d[e];
-        if (acc_ == 12345.678f) Vb[0] = acc_;
-      }
-      return;
-    }
     float q[16];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -278,14 +193,6 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
       q[4 + c] = d[4 + c] + d[8 + c];
       q[8 + c] = d[8 + c] - d[4 + c];
       q[12 + c] = d[4 + c] - d[12 + c];
-    }
-    if constexpr (HG_WINO_DBG & 8) {
-      float acc_ = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc_ += (q[4 * r] - q[4 * r + 2]) + (q[4 * r + 1] + q[4 * r + 2]) + (q[4 * r + 2] - q[4 * r + 1]) * 3.f + (q[4 * r + 1] - q[4 * r + 3]) * 5.f;
-      if (acc_ == 12345.678f) Vb[0] = acc_;
-      return;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -298,177 +205,38 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   auto mfma_chunk = [&](int buf, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
     const float *Vc = smem + buf * VSZ + lk * TB + lm;
-    if constexpr (HG_WINO_DBG & 16) {
-      float t_ = 0.f;
 #pragma unroll
-      for (int x2 = 0; x2 < 2; ++x2)
+    for (int x2 = 0; x2 < 2; ++x2)
 #pragma unroll
-        for (int e = 0; e < NV; ++e) t_ += ua[S][x2][e];
-      acc[0][0][0][0] += t_ + Vc[0];
-      return;
-    }
-    // B operands one MFMA step ahead (two register slots), the order pinned: [reads of step s + 1][MFMAs of step s].  Left
-    // to itself the compiler issues a step's reads right in front of its MFMAs, behind an s_waitcnt: the wave then idles an
-    // LDS round trip per step, and the matrix pipe with it unless the SIMD's other wave happens to have MFMAs queued (a
-    // wave ALONE needed 3400 instead of 2048 cycles for a chunk's 32 MFMAs: the ping-pong experiment).
-    constexpr int NS = 2 * (KC / 2);
-    float bv[2][TP];
-    auto ldop = [&](int s_, int slot) __attribute__((always_inline)) {
-      const int x2 = s_ / (KC / 2), ks = s_ % (KC / 2);
+      for (int ks = 0; ks < KC / 2; ++ks) {
+        float bv[TP];
 #pragma unroll
-      for (int j = 0; j < TP; ++j) bv[slot][j] = Vc[((2 * wave + x2) * KC + 2 * ks) * TB + 32 * j];
-    };
-    ldop(0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, (TP + 1) / 2, 0);
+        for (int j = 0; j < TP; ++j) bv[j] = Vc[((2 * wave + x2) * KC + 2 * ks) * TB + 32 * j];
 #pragma unroll
-    for (int s_ = 0; s_ < NS; ++s_) {
-      const int x2 = s_ / (KC / 2), ks = s_ % (KC / 2);
-      if (s_ + 1 < NS) ldop(s_ + 1, (s_ + 1) & 1);
+        for (int i = 0; i < TC; ++i)
 #pragma unroll
-      for (int i = 0; i < TC; ++i)
-#pragma unroll
-        for (int j = 0; j < TP; ++j)
-          acc[x2][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[S][x2][ks * TC + i], bv[s_ & 1][j], acc[x2][i][j], 0, 0, 0);
-      if (s_ + 1 < NS) __builtin_amdgcn_sched_group_barrier(0x100, (TP + 1) / 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, TC * TP, 0);
-    }
+          for (int j = 0; j < TP; ++j)
+            acc[x2][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[S][x2][ks * TC + i], bv[j], acc[x2][i][j], 0, 0, 0);
+      }
   };
-
-  // K chunks of this split, two phases per trip (V buffer / register sets 0, then 1).  Phase c: request the patch of chunk
-  // c + 2 FIRST (into the set the previous phase's transform just freed), multiply chunk c, transform the patch of chunk
-  // c + 1 (requested a whole phase ago: the compiler may interleave these additions with the MFMAs without exposing the
-  // load latency), then request the weights of chunk c + 2 into the set the MFMAs just released; ONE barrier.
-  // Every load of the loop body is UNCONDITIONAL (past the end the chunk index is clamped: a redundant load nobody
-  // consumes): with loads behind branches the compiler has to assume the shortest path and waits for (almost) every
-  // outstanding load before the first MFMA of a chunk.  sched_barrier at the phase boundaries: the scheduler otherwise
-  // hoists the first additions of the NEXT transform across the barrier, right behind the loads they consume.
-  const int cps = (a.nch + a.ksplit - 1) / a.ksplit;
-  const int c_begin = zs * cps;
-  const int c_end = c_begin + cps < a.nch ? c_begin + cps : a.nch;
-  const int nc = c_end - c_begin;
-  typedef std::integral_constant<int, 0> S0;
-  typedef std::integral_constant<int, 1> S1;
   auto clampc = [&](int c) __attribute__((always_inline)) { return c < c_end ? c : c_end - 1; };
-
-  // The order of a phase's instructions, one group per MFMA step (a B-operand read, its TC x TP MFMAs, then a share of the
-  // phase's global loads, transform arithmetic and V stores): the loads are requests for chunk c + 2 and can go anywhere in
-  // the phase -- issued as a block in front (12 per wave, 8 waves) they hold every wave of the CU at the head of the phase
-  // while the memory pipeline takes them in (ablation: 16 % of the kernel; tools/wino_ablate.py), spread between the MFMA
-  // groups they are absorbed while the matrix pipe drains its queue.
-  [[maybe_unused]] auto phase_schedule = [&]() __attribute__((always_inline)) {
-#if !HG_WINO_SPLIT_PHASE && HG_WINO_SCHED
-    constexpr int NG = 2 * (KC / 2);                           // MFMA steps per phase
-    constexpr int NLD = 12 + (NV >= 4 ? 2 * (NV / 4) : 2) + (FE ? 1 : 0);   // global loads per phase
-    constexpr int LPG = (NLD + NG - 1) / NG;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // DS read (one ds_read2 = the step's B operands)
-      __builtin_amdgcn_sched_group_barrier(0x008, TC * TP, 0);  // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x020, LPG, 0);      // VMEM read
-      __builtin_amdgcn_sched_group_barrier(0x002, 48 / NG, 0);  // VALU (transform)
-      __builtin_amdgcn_sched_group_barrier(0x200, 8 / NG > 0 ? 8 / NG : 1, 0);   // DS write
-    }
-#endif
-  };
-
-#if HG_WINO_PINGPONG
-  // PING-PONG: the two waves that share a SIMD (wave w and w + 4: a workgroup's waves go to the SIMDs round robin) run the
-  // two halves of a chunk in opposite order, one barrier per half: while waves 0-3 multiply chunk c, waves 4-7 transform
-  // their patches of chunk c + 1 and issue their loads, then the roles swap.  With every wave in the same phase (the
-  // one-barrier loop) the transform / load / barrier time of a chunk ADDS to its MFMA time (ablation: 4096 + 900 + 600
-  // cycles per chunk) -- nothing is left on the SIMD to overlap it with; here the matrix pipe always has the other wave's
-  // MFMAs queued.  V(c + 1) is complete after both halves, i.e. before either group multiplies it; a V buffer is
-  // rewritten two halves after its last reader.  A transform frees its patch registers, so the patch of chunk c + 3 is
-  // requested right behind it (two chunks ahead), the weights of chunk c + 2 behind the MFMAs of chunk c.
-  // Both groups run the SAME instruction stream, group 1 half a chunk behind in MFMAs / ahead in transforms:
-  //   step     0    1    2    3    4    5
-  //   group 0  M0   T1   M1   T2   M2   T3 ..      (Mc = the MFMAs of chunk c, Tc = transform + store of the own patches
-  //   group 1  T1   M0   T2   M1   T3   M2 ..       of chunk c, then the request for the next patch into the freed registers)
-  // so only the chunk a transform works on and its V buffer differ (run-time scalars); the register sets are the same.
-  const int pgrp = __builtin_amdgcn_readfirstlane(wave >> 2);   // (scalar: it enters buffer descriptors and LDS bases)
-#define HG_WINO_HALF_BARRIER()          \
+#define HG_WINO_BARRIER()               \
   __builtin_amdgcn_sched_barrier(0);    \
   __syncthreads();                      \
   __builtin_amdgcn_sched_barrier(0)
-  if (nc > 0) {
-    load_patch(c_begin, S0{});
-    load_u(c_begin, S0{});
-    load_patch(clampc(c_begin + 1), S1{});
-    load_u(clampc(c_begin + 1), S1{});
-    transform_store(0, S0{});
-    load_patch(clampc(c_begin + 2 + pgrp), S0{});
-    HG_WINO_HALF_BARRIER();
-    if (pgrp) {                       // step 0 of group 1: T1
-      transform_store(1, S1{});
-      load_patch(clampc(c_begin + 2), S1{});
-      HG_WINO_HALF_BARRIER();
-    }
-    for (int c = c_begin; c + 1 < c_end; c += 2) {
-      mfma_chunk(0, S0{});
-      load_u(clampc(c + 2), S0{});
-      HG_WINO_HALF_BARRIER();
-      transform_store(pgrp ^ 1, S1{});
-      load_patch(clampc(c + 3 + pgrp), S1{});
-      HG_WINO_HALF_BARRIER();
-      mfma_chunk(1, S1{});
-      load_u(clampc(c + 3), S1{});
-      HG_WINO_HALF_BARRIER();
-      transform_store(pgrp, S0{});
-      load_patch(clampc(c + 4 + pgrp), S0{});
-      HG_WINO_HALF_BARRIER();
-    }
-    if (!pgrp) { HG_WINO_HALF_BARRIER(); }   // group 0 started a half earlier: the same number of barriers for every wave
-    if (nc & 1) mfma_chunk(0, S0{});
-  }
-#undef HG_WINO_HALF_BARRIER
-#else
-  if (nc > 0) {
-    load_patch(c_begin, S0{});
-    load_u(c_begin, S0{});
-    load_patch(clampc(c_begin + 1), S1{});
-    load_u(clampc(c_begin + 1), S1{});
-    transform_store(0, S0{});
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
-    for (int c = c_begin; c + 1 < c_end; c += 2) {
-      load_patch(clampc(c + 2), S0{});
-#if HG_WINO_SPLIT_PHASE || !HG_WINO_SCHED
-      __builtin_amdgcn_sched_barrier(0);   // (the loads stay in front: the scheduler would sink them behind the MFMAs)
-#endif
-      mfma_chunk(0, S0{});
-#if HG_WINO_SPLIT_PHASE
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      transform_store(1, S1{});
-      load_u(clampc(c + 2), S0{});
-      phase_schedule();
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-      load_patch(clampc(c + 3), S1{});
-#if HG_WINO_SPLIT_PHASE || !HG_WINO_SCHED
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      mfma_chunk(1, S1{});
-#if HG_WINO_SPLIT_PHASE
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-      transform_store(0, S0{});
-      load_u(clampc(c + 3), S1{});
-      phase_schedule();
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (nc & 1) mfma_chunk(0, S0{});
-  }
 
-#endif
-
-  // ---- epilogue: one (channel tile, tile tile) pair at a time through LDS
-  if constexpr (HG_WINO_DBG & 32) {
-    float t_ = 0.f;
+  // PERSISTENT: one workgroup per CU walks over the launch's tiles, and the first chunk of the NEXT tile (its patch and its
+  // weights) is requested before the epilogue of the current one -- a tile otherwise starts with a full global round trip
+  // in front of its first MFMA and ends with ~5 us of LDS exchange + stores during which nothing is in flight.
+  int L = blockIdx.x;
+  if (L < a.total_tiles) {
+    tile_setup(L);
+    if (c_begin < c_end) {
+      load_patch(c_begin, S0{});
+      load_u(c_begin, S0{});
+    }
+  }
+  for (; L < a.total_tiles; L += gridDim.x) {
 #pragma unroll
     for (int x2 = 0; x2 < 2; ++x2)
 #pragma unroll
@@ -476,13 +244,57 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
 #pragma unroll
         for (int j = 0; j < TP; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) t_ += acc[x2][i][j][r];
-    if (t_ == 12345.678f) a.out[tid] = t_;
-    __syncthreads();
-    continue;
-  }
+          for (int r = 0; r < 16; ++r) acc[x2][i][j][r] = 0.f;
+
+    // K chunks of this tile, two phases per trip (V buffer / register sets 0, then 1).  Phase c: request the patch of chunk
+    // c + 2 FIRST (into the set the previous phase's transform freed), multiply chunk c while transforming the patch of
+    // chunk c + 1 (requested a whole phase ago: the compiler interleaves these additions with the MFMAs without exposing the
+    // load latency), then request the weights of chunk c + 2 into the set the MFMAs released; ONE barrier.  Every load of
+    // the loop body is UNCONDITIONAL (past the end the chunk index is clamped: a redundant load nobody consumes): with loads
+    // behind branches the compiler assumes the shortest path and waits for (almost) every outstanding load before the first
+    // MFMA of a chunk.  sched_barrier at the phase boundaries: the scheduler otherwise hoists the first additions of the
+    // NEXT transform across the barrier, right behind the loads they consume, or sinks the phase's loads behind its MFMAs.
+    // (Measured and rejected, profiles/r05_wino_ablation.txt, the code is in the history at commit f419444: the loads spread between the MFMA
+    // steps with sched_group_barrier, +10 %; the two waves of a SIMD in opposite halves of a chunk with two barriers
+    // ("ping-pong"), +5 %; MFMAs and transform as separate scheduling regions, +-0.)
+    const int nc = c_end - c_begin;
+    if (nc > 0) {
+      load_patch(clampc(c_begin + 1), S1{});
+      load_u(clampc(c_begin + 1), S1{});
+      transform_store(0, S0{});
+      HG_WINO_BARRIER();
+      for (int c = c_begin; c + 1 < c_end; c += 2) {
+        load_patch(clampc(c + 2), S0{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(0, S0{});
+        transform_store(1, S1{});
+        load_u(clampc(c + 2), S0{});
+        HG_WINO_BARRIER();
+        load_patch(clampc(c + 3), S1{});
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_chunk(1, S1{});
+        transform_store(0, S0{});
+        load_u(clampc(c + 3), S1{});
+        HG_WINO_BARRIER();
+      }
+      if (nc & 1) mfma_chunk(0, S0{});
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // the finished tile's coordinates for the epilogue; then the next tile's set-up and first requests
+    const int e_n0 = nb * NB, e_bx = bx, e_by = by, e_b0 = b0, e_zs = zs;
+    if (L + (int)gridDim.x < a.total_tiles) {
+      tile_setup(L + (int)gridDim.x);
+      if (c_begin < c_end) {
+        load_patch(c_begin, S0{});
+        load_u(c_begin, S0{});
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+  // ---- epilogue: one (channel tile, tile tile) pair at a time through LDS
   const bool fin = a.ksplit == 1;
-  float *ob = fin ? a.out : a.slab + (size_t)zs * a.B * N * HW;
+  float *ob = fin ? a.out : a.slab + (size_t)e_zs * a.B * N * HW;
   const int erow = tid >> 5, ecol = tid & 31;
   // Epilogue operands, requested BEFORE the first pass so that their latency runs under the LDS exchange (read where they
   // are used, each pass waited for a global round trip of its own): per-channel bias / noise weight of this thread's 2 TC
@@ -495,7 +307,7 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   for (int j = 0; j < TP; ++j) {
     const int tl = 32 * j + ecol;
     const int ttx = tl & TWm, tty = (tl >> a.lTW) & THm, timg = tl >> (a.lTW + a.lTH);
-    etx[j] = (bx << a.lTW) + ttx; ety[j] = (by << a.lTH) + tty; etb[j] = b0 + timg;
+    etx[j] = (e_bx << a.lTW) + ttx; ety[j] = (e_by << a.lTH) + tty; etb[j] = e_b0 + timg;
     eok[j] = etx[j] < a.tiles_w && ety[j] < a.tiles_h && etb[j] < a.B;
 #pragma unroll
     for (int p2 = 0; p2 < 2; ++p2) {
@@ -508,7 +320,7 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   for (int i = 0; i < TC; ++i)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int n = n0 + 32 * i + erow + 16 * h, nc_ = n < N ? n : N - 1;
+      const int n = e_n0 + 32 * i + erow + 16 * h, nc_ = n < N ? n : N - 1;
       ebias[i][h] = (fin && a.bias) ? a.bias[nc_] : 0.f;
       enw[i][h] = (fin && a.noise_img) ? a.noise_w[nc_] : 0.f;
 #pragma unroll
@@ -525,7 +337,7 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
 #pragma unroll
         for (int p2 = 0; p2 < 2; ++p2) {
           ead[h][p2] = f32x2{0.f, 0.f};
-          const int n = n0 + 32 * i + erow + 16 * h;
+          const int n = e_n0 + 32 * i + erow + 16 * h;
           if (fin && a.addend && eok[j] && n < N)
             ead[h][p2] = *reinterpret_cast<const f32x2 *>(a.addend + (((size_t)etb[j] * N + n) * H + 2 * ety[j] + p2) * W + 2 * etx[j]);
         }
@@ -538,7 +350,7 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int row = erow + 16 * h;
-        const int n = n0 + 32 * i + row;
+        const int n = e_n0 + 32 * i + row;
         float m[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) m[e] = smem[(e * 32 + row) * 32 + ecol];
@@ -570,8 +382,9 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
       }
     }
   }
-  __syncthreads();   // the next tile's first transform writes the V buffer this staging area aliases
+    __syncthreads();   // the next tile's first transform writes the V buffer this staging area aliases
   }
+#undef HG_WINO_BARRIER
 }
 
 // out = epilogue(sum_z slab[z]) in fixed order (as k_splitk_reduce of hg_conv.hip)
@@ -1138,11 +951,11 @@ extern "C" {
 int hg_wino_supported(int32_t B, int32_t K, int32_t N, int32_t H, int32_t W) {
   WinoPlan p;
   if (!make_plan(B, K, N, H, W, p)) return 0;
-  // measured against the direct kernel at the C3 shapes (tools/wino_probe.py, profiles/r05_wino_probe.txt): the 64-channel
-  // variant wins from 32 input channels on (1.15x at 32 -> 64, 1.4-1.9x from 64 up), the 32-channel variant (twice the
-  // transform work per MFMA) only with >= 64 input channels (1.19x at 64 -> 32 @256^2; 0.94-1.09x at 32 -> 32)
+  // measured against the direct kernel at the C3 shapes (tools/wino_probe.py, profiles/r05_wino_probe_v5.txt): both variants
+  // win from 32 input channels on -- the 64-channel variant 1.27x at 32 -> 64 and 1.5-2.2x from 64 up, the 32-channel variant
+  // (twice the transform work per MFMA) 1.15-1.23x at 32 -> 32 and 1.38x at 64 -> 32 @256^2; 16 -> 32 loses (0.8-0.93x)
   static const int min_k0 = getenv("HG_WINO_MIN_K") ? atoi(getenv("HG_WINO_MIN_K")) : 32;
-  static const int min_k1 = getenv("HG_WINO_MIN_K1") ? atoi(getenv("HG_WINO_MIN_K1")) : 64;
+  static const int min_k1 = getenv("HG_WINO_MIN_K1") ? atoi(getenv("HG_WINO_MIN_K1")) : 32;
   if (K < (p.variant ? min_k1 : min_k0)) return 0;
   return p.blocks * p.ksplit >= num_cus() / 2;
 }

@@ -218,7 +218,7 @@ def test_wino_host_logic(L):
     # served shapes (256 CUs assumed without a GPU)
     assert lib.hg_wino_supported(32, 256, 128, 64, 64) == 1 and lib.hg_wino_supported(64, 1024, 2048, 2, 2) == 1
     assert lib.hg_wino_supported(32, 256, 128, 64, 63) == 0 and lib.hg_wino_supported(32, 16, 32, 128, 128) == 0
-    assert lib.hg_wino_supported(32, 32, 32, 256, 256) == 0 and lib.hg_wino_supported(32, 64, 32, 256, 256) == 1
+    assert lib.hg_wino_supported(32, 32, 32, 256, 256) == 1 and lib.hg_wino_supported(32, 64, 32, 256, 256) == 1
     assert lib.hg_wino_wgrad_supported(32, 256, 128, 64, 64) == 1 and lib.hg_wino_wgrad_supported(32, 2048, 2048, 4, 4) == 1
     assert lib.hg_wino_wgrad_supported(64, 1024, 2048, 2, 2) == 0 and lib.hg_wino_wgrad_supported(32, 32, 64, 64, 64) == 0
     # a launch that cannot fill the chip with output tiles splits K into slabs; a full one needs no scratch
