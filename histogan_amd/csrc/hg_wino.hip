@@ -1040,7 +1040,7 @@ int hg_wino_wgrad_supported(int32_t B, int32_t K, int32_t N, int32_t H, int32_t 
   if (!make_wg_plan(B, K, N, H, W, p)) return 0;
   // 64 x 64 channel tiles: a layer with fewer channels on a side multiplies padding (and the transforms, done once per
   // 64 x 64 tile, stop amortising: 0.75x at 32 -> 64); 2x2 maps are slab traffic rather than arithmetic (0.84-0.95x);
-  // measured 1.25-1.9x elsewhere (tools/wino_probe.py, profiles/r05_wino_probe_v3.txt)
+  // measured 1.25-1.9x elsewhere (tools/wino_probe.py, profiles/r05_wino_probe_v5.txt)
   static const int min_c = getenv("HG_WINO_WG_MIN_C") ? atoi(getenv("HG_WINO_WG_MIN_C")) : 64;
   static const int min_s = getenv("HG_WINO_WG_MIN_S") ? atoi(getenv("HG_WINO_WG_MIN_S")) : 4;
   if (K < min_c || N < min_c || H < min_s || W < min_s) return 0;
