@@ -78,6 +78,12 @@ def _load():
     lib.hg_modulate_bwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]
     lib.hg_nets_workspace_bytes.restype = sz
     lib.hg_nets_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    lib.hg_torgb_fwd.restype = ctypes.c_int
+    lib.hg_torgb_fwd.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.hg_torgb_bwd_workspace_bytes.restype = sz
+    lib.hg_torgb_bwd_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    lib.hg_torgb_bwd.restype = ctypes.c_int
+    lib.hg_torgb_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]
     lib.hg_channel_sum.restype = ctypes.c_int
     lib.hg_channel_sum.argtypes = [vp, vp, i32, i32, i32, vp, sz, vp]
     lib.hg_demod_noise_lrelu_fwd.restype = ctypes.c_int
@@ -204,7 +210,8 @@ EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg
            'hg_augment_color', 'hg_grouped_linear_fwd', 'hg_grouped_linear_bwd_input_workspace_bytes',
            'hg_grouped_linear_bwd_input', 'hg_grouped_linear_bwd_params',
            'hg_wino_supported', 'hg_wino_packed_elems', 'hg_wino_pack_weights', 'hg_wino_pack_blocks', 'hg_wino_pack_weights_multi', 'hg_wino_workspace_bytes', 'hg_wino_conv2d',
-           'hg_wino_wgrad_supported', 'hg_wino_wgrad_workspace_bytes', 'hg_wino_wgrad')
+           'hg_wino_wgrad_supported', 'hg_wino_wgrad_workspace_bytes', 'hg_wino_wgrad',
+           'hg_torgb_fwd', 'hg_torgb_bwd_workspace_bytes', 'hg_torgb_bwd')
 
 
 class HgError(RuntimeError):

@@ -107,6 +107,11 @@ class RGBBlock(nn.Module):
         return self.forward_(x, prev_rgb, self.to_style(istyle))
 
     def forward_(self, x, prev_rgb, style):
+        if (not self.conv.demod and self.conv.kernel == 1 and self.conv.stride == 1 and self.conv.dilation == 1
+                and ops.torgb_supported(x, self.conv.weight) and style.dtype == torch.float32):
+            # the 1x1 modulated convolution onto 3 channels + the running RGB image as one stream over x (ops._ToRGB)
+            x = ops.torgb(x, style, self.conv.weight, prev_rgb)
+            return ops.upsample2x(x) if self.upsample is not None else x
         if GeneratorBlock._fused() and x.is_cuda and not self.conv.demod and self.conv.kernel == 1:
             x = ops.modconv_stage(x, style, self.conv.weight, demod=False, upsample=False, act=False)
         else:

@@ -140,6 +140,57 @@ def demod_noise_lrelu(conv, d, nzt, wn, bn):
     return _DemodNoiseLrelu.apply(conv, d, nzt, wn, bn)
 
 
+TORGB = os.environ.get('HG_TORGB', '1') != '0'      # the to-RGB path as one stream over x per direction (hg_torgb_fwd / _bwd)
+
+
+def torgb_supported(x, weight):
+    return (TORGB and x.is_cuda and x.dtype == torch.float32 and weight.shape[2] == 1 and weight.shape[3] == 1
+            and weight.shape[0] <= 4 and (x.shape[2] * x.shape[3]) % 4 == 0 and weight.shape[0] * weight.shape[1] * 4 <= 48 * 1024)
+
+
+class _ToRGB(torch.autograd.Function):
+    """rgb = conv1x1(x * (style + 1), W) [+ prev]: RGBBlock's modulated convolution without demodulation plus the running RGB
+    image (histoGAN/histoGAN.py:380-390) as ONE pass over x forward (hg_torgb_fwd) and ONE backward (hg_torgb_bwd: gx, the
+    style gradient and the weight gradient from the same read of x) -- instead of a modulated copy of x, a 3-row matrix
+    launch and a residual add forward, and data gradient + weight gradient + modulation adjoint backward.  First order."""
+
+    @staticmethod
+    def forward(ctx, x, style, weight, prev):
+        x_, s_, w_ = _f32c(x.detach()), _f32c(style.detach()), _f32c(weight.detach())
+        B, O, H, W = x_.shape
+        C = w_.shape[0]
+        p_ = None if prev is None else _f32c(prev.detach())
+        with on_device(x_.device):
+            out = torch.empty((B, C, H, W), dtype=torch.float32, device=x_.device)
+            check(lib.hg_torgb_fwd(x_.data_ptr(), s_.data_ptr(), w_.data_ptr(), None if p_ is None else p_.data_ptr(),
+                                   out.data_ptr(), B, O, C, H * W, _st(x_)), 'hg_torgb_fwd')
+        ctx.save_for_backward(x_, s_, w_)
+        ctx.has_prev = prev is not None
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x_, s_, w_ = ctx.saved_tensors
+        g = _f32c(g.detach())
+        B, O, H, W = x_.shape
+        C = w_.shape[0]
+        with on_device(x_.device):
+            gx = torch.empty_like(x_)
+            gs = torch.empty_like(s_)
+            gw = torch.empty_like(w_)
+            nb = lib.hg_torgb_bwd_workspace_bytes(B, O, C, H * W)
+            ws = torch.empty(nb, dtype=torch.uint8, device=x_.device)
+            check(lib.hg_torgb_bwd(g.data_ptr(), x_.data_ptr(), s_.data_ptr(), w_.data_ptr(), gx.data_ptr(), gs.data_ptr(),
+                                   gw.data_ptr(), B, O, C, H * W, ws.data_ptr(), nb, _st(x_)), 'hg_torgb_bwd')
+        return gx, gs, gw, (g if ctx.has_prev else None)
+
+
+def torgb(x, style, weight, prev=None):
+    """conv1x1(x * (style + 1), weight) + prev in one launch per direction -- see _ToRGB."""
+    return _ToRGB.apply(x, style, weight, prev)
+
+
 FUSED_DNL = os.environ.get('HG_FUSED_DNL', '1') != '0'   # conv + demodulation + noise + LeakyReLU as one forward launch in training
 
 

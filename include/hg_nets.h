@@ -32,6 +32,22 @@ int hg_modulate_bwd(const float *gout, const float *x, const float *s, float *gx
                     int32_t C, int32_t H, int32_t W, int32_t upsample, void *workspace, size_t workspace_bytes,
                     void *stream);
 
+/* The to-RGB path of a generator block as ONE stream over x (RGBBlock.forward, histoGAN/histoGAN.py:380-390: the 1x1
+ * modulated convolution without demodulation onto C = 3 (4: rgba) channels, plus the previous block's RGB image):
+ *   out[b,c,p] = sum_o w[c,o] * (s[b,o] + 1) * x[b,o,p] + prev[b,c,p]
+ * x (B,O,HW), s (B,O) or NULL, w (C,O), prev (B,C,HW) or NULL, out (B,C,HW); HW % 4 == 0, C <= 4, C*O*4 B of LDS
+ * (HG_EUNSUPPORTED otherwise: the caller takes the modulated-convolution path). */
+int hg_torgb_fwd(const float *x, const float *s, const float *w, const float *prev, float *out, int32_t B, int32_t O,
+                 int32_t C, int32_t HW, void *stream);
+/* Its adjoint from ONE pass over x and the C-channel gradient g (B,C,HW):
+ *   gx[b,o,p] = (s[b,o] + 1) * sum_c w[c,o] g[b,c,p]
+ *   gs[b,o]   = sum_p x[b,o,p] * sum_c w[c,o] g[b,c,p]          (NULL iff s is NULL)
+ *   gw[c,o]   = sum_{b,p} g[b,c,p] * (s[b,o] + 1) * x[b,o,p]
+ * (the gradient of prev is g itself).  Deterministic: per-block partial sums in the workspace, combined in fixed order. */
+size_t hg_torgb_bwd_workspace_bytes(int32_t B, int32_t O, int32_t C, int32_t HW);
+int hg_torgb_bwd(const float *g, const float *x, const float *s, const float *w, float *gx, float *gs, float *gw, int32_t B,
+                 int32_t O, int32_t C, int32_t HW, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Scratch (partial sums, combined in fixed order: deterministic) for hg_modulate_bwd / hg_demod_noise_lrelu_bwd /
  * hg_channel_sum on a (B, C, H, W) tensor. */
 size_t hg_nets_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W);

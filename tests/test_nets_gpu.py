@@ -500,3 +500,63 @@ def test_upsample_adjoint_paths_agree(shape, gpu_device):
     assert go2.data_ptr() % 16 != 0
     gx2, gs2 = torch.autograd.grad(ops.modulate(x, s, True), (x, s), go2)
     assert torch.equal(gx2, gx) and relmax(gs2.cpu().numpy(), gs.cpu().numpy()) <= 1e-6
+
+
+@pytest.mark.parametrize('B,O,C,S,with_prev', [(2, 32, 3, 16, True), (3, 2048, 3, 4, True), (2, 64, 3, 128, True), (5, 40, 4, 8, False),
+                                               (1, 512, 3, 2, False), (32, 32, 3, 64, True), (2, 100, 3, 6, True)])
+def test_torgb_matches_fp64(B, O, C, S, with_prev, gpu_device):
+    """ops.torgb (hg_torgb_fwd / hg_torgb_bwd: RGBBlock's 1x1 modulated convolution without demodulation + the running RGB
+    image, histoGAN/histoGAN.py:380-390, as one stream over x per direction) against the formula in fp64: output and the
+    gradients of x, style, weight and prev; deterministic; == the modulated-convolution path it replaces."""
+    from histogan_amd import ops
+    dev = gpu_device
+    g = torch.Generator().manual_seed(B * 7 + O + S)
+    x = torch.randn(B, O, S, S, generator=g).to(dev).requires_grad_(True)
+    st = (0.4 * torch.randn(B, O, generator=g)).to(dev).requires_grad_(True)
+    w = (torch.randn(C, O, 1, 1, generator=g) / O ** 0.5).to(dev).requires_grad_(True)
+    prev = torch.randn(B, C, S, S, generator=g).to(dev).requires_grad_(True) if with_prev else None
+    go = torch.randn(B, C, S, S, generator=g).to(dev)
+    assert ops.torgb_supported(x, w)
+    out = ops.torgb(x, st, w, prev)
+    ins = [x, st, w] + ([prev] if with_prev else [])
+    grads = torch.autograd.grad(out, ins, go)
+    xd, sd, wd = (t.detach().double().requires_grad_(True) for t in (x, st, w))
+    pd = prev.detach().double().requires_grad_(True) if with_prev else None
+    ref = torch.einsum('co,bo,bohw->bchw', wd[:, :, 0, 0], sd + 1.0, xd)
+    if with_prev:
+        ref = ref + pd
+    rgrads = torch.autograd.grad(ref, [xd, sd, wd] + ([pd] if with_prev else []), go.double())
+    assert out.shape == ref.shape and relmax(out.detach().cpu().numpy(), ref.detach().cpu().numpy()) <= 2e-6
+    for a, r in zip(grads, rgrads):
+        assert a.shape == r.shape and relmax(a.cpu().numpy(), r.cpu().numpy()) <= 5e-6, (a.shape,)
+    out2 = ops.torgb(x, st, w, prev)
+    grads2 = torch.autograd.grad(out2, ins, go)
+    assert torch.equal(out, out2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
+
+
+def test_rgbblock_torgb_path_equals_modconv_path(gpu_device):
+    """RGBBlock.forward_ on the fused to-RGB kernels == the same block on the modulated-convolution path (HG_TORGB off)."""
+    from histogan_amd import ops
+    from histoGAN import RGBBlock
+    torch.manual_seed(3)
+    dev = gpu_device
+    blk = RGBBlock(64, 48, upsample=True).to(dev)
+    x = torch.randn(3, 48, 16, 16, device=dev, requires_grad=True)
+    prev = torch.randn(3, 3, 16, 16, device=dev, requires_grad=True)
+    ist = torch.randn(3, 64, device=dev, requires_grad=True)
+    go = torch.randn(3, 3, 32, 32, device=dev)
+    params = list(blk.parameters())
+
+    def run():
+        out = blk(x, prev, ist)
+        return out, torch.autograd.grad(out, [x, prev, ist] + params, go)
+    o1, g1 = run()
+    saved = ops.TORGB
+    try:
+        ops.TORGB = False
+        o2, g2 = run()
+    finally:
+        ops.TORGB = saved
+    assert relmax(o1.detach().cpu().numpy(), o2.detach().cpu().numpy()) <= 2e-6
+    for a, b in zip(g1, g2):
+        assert relmax(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
