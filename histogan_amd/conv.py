@@ -12,6 +12,7 @@ gradient penalty (histoGAN/histoGAN.py:156-163) needs the second order.
 import contextlib
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -108,7 +109,7 @@ def modconv_fwd_packed(x, wt, N, ksize, iscale=None, oscale=None, bias=None, noi
         out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
         nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, 1, 0)
         ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
-        check(lib.hg_modconv2d_fwd(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(iscale), _ptr(oscale), _ptr(bias),
+        check(lib.hg_modconv2d_fwd(x.data_ptr(), _direct_operand(wt).data_ptr(), out.data_ptr(), _ptr(iscale), _ptr(oscale), _ptr(bias),
                                    _ptr(noise_w), _ptr(noise_img), noise_S, float(slope), B, K, N, H, W, ksize, _ptr(ws), nb,
                                    _st(x)), 'hg_modconv2d_fwd')
     return out
@@ -277,7 +278,7 @@ class _PackItem(ctypes.Structure):       # include/hg_conv.h: hg_pack_item
 
 
 class _WinoItem(ctypes.Structure):       # include/hg_wino.h: hg_wino_pack_item
-    _fields_ = [('w', ctypes.c_void_p), ('u_fwd', ctypes.c_void_p), ('u_dgrad', ctypes.c_void_p),
+    _fields_ = [('w', ctypes.c_void_p), ('u_fwd', ctypes.c_void_p), ('u_dgrad', ctypes.c_void_p), ('wsq', ctypes.c_void_p),
                 ('Co', ctypes.c_int32), ('Ci', ctypes.c_int32), ('block_begin', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
@@ -286,6 +287,24 @@ def build_pack_plans(device):
     e.g. before a hipGraph capture, inside which a plan cannot be built."""
     for owner in {own for own, _ in _cacheable.values()}:
         _pack_owner(owner, device, launch=False)
+
+
+LAZY_DIRECT = os.environ.get('HG_LAZY_DIRECT', '1') != '0'   # no direct pack for weights only ever used through Winograd
+_direct_needed = set()    # keys of registered 3x3 weights whose DIRECT operands some launch asked for
+
+
+def _direct_operand(wt):
+    """`wt` as the operand of a DIRECT launch: packed now if the batched pack skipped it (see _pack_owner)."""
+    if getattr(wt, 'direct_stale', False):
+        ref, mode, key = wt.pack_src
+        p = ref()
+        if p is not None:
+            Co, Ci, k, _ = p.shape
+            with on_device(p.device):
+                check(lib.hg_conv_pack_weights(p.data_ptr(), wt.data_ptr(), Co, Ci, k, mode, _st(p)), 'hg_conv_pack_weights')
+            wt.direct_stale = False
+            _direct_needed.add(key)
+    return wt
 
 
 PACK_SPLIT = float(os.environ.get('HG_PACK_SPLIT', '0'))   # share of a buffer's weights in the first pack group (0: one group)
@@ -307,7 +326,7 @@ def _pack_owner(owner, device, launch=True, record_on=None):
             live.append((key, p))
     if not live:
         return False
-    sig = tuple(k for k, _ in live)
+    sig = (tuple(k for k, _ in live), frozenset(k for k, _ in live if k in _direct_needed))
     plan = _multi.get(owner)
     with on_device(device):
         if plan is None or plan['sig'] != sig:
@@ -321,7 +340,7 @@ def _pack_owner(owner, device, launch=True, record_on=None):
                 run += p.numel()
                 ncut += 1
             cuts = [(0, ncut), (ncut, len(live))] if 0 < ncut < len(live) else [(0, len(live))]
-            bufs, groups = {}, []
+            bufs, groups, lazy = {}, [], set()
             for lo, hi in cuts:
                 items, witems, blocks, wblocks = [], [], 0, 0
                 for key, p in live[lo:hi]:
@@ -331,32 +350,47 @@ def _pack_owner(owner, device, launch=True, record_on=None):
                     # sum over the taps of W^2 (the demodulation coefficient's weight factor), from the same tile
                     wq = torch.empty((Co, Ci), dtype=torch.float32, device=device)
                     bufs[key] = (wf, wd, wq)
-                    items.append(_PackItem(p.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, blocks, wq.data_ptr()))
-                    blocks += lib.hg_conv_pack_blocks(Co, Ci)
                     wf.wino = wd.wino = False
+                    nf = nd = 0
                     if WINO and k == 3:        # the Winograd operands of the 3x3 weights (include/hg_wino.h), one more launch
                         nf, nd = lib.hg_wino_packed_elems(Co, Ci, PACK_FWD), lib.hg_wino_packed_elems(Co, Ci, PACK_DGRAD)
                         if nf:
                             wf.wino = torch.empty(nf, dtype=torch.float32, device=device)
                         if nd:
                             wd.wino = torch.empty(nd, dtype=torch.float32, device=device)
-                        if nf or nd:
-                            witems.append(_WinoItem(p.data_ptr(), wf.wino.data_ptr() if nf else None,
-                                                    wd.wino.data_ptr() if nd else None, Co, Ci, wblocks, 0))
-                            wblocks += lib.hg_wino_pack_blocks(Co, Ci, int(bool(nf)), int(bool(nd)))
+                    # A weight whose launches all take the Winograd operands needs no direct pack: its direct operands are
+                    # left stale (`direct_stale`) until a launch asks for them -- _direct_operand packs that one weight then
+                    # and puts it on the `_direct_needed` list, i.e. into the batched launch from the next plan on.
+                    skip = LAZY_DIRECT and nf and nd and key not in _direct_needed
+                    if skip:
+                        lazy.add(key)
+                    else:
+                        items.append(_PackItem(p.data_ptr(), wf.data_ptr(), wd.data_ptr(), Co, Ci, k, blocks, wq.data_ptr()))
+                        blocks += lib.hg_conv_pack_blocks(Co, Ci)
+                    if nf or nd:
+                        witems.append(_WinoItem(p.data_ptr(), wf.wino.data_ptr() if nf else None,
+                                                wd.wino.data_ptr() if nd else None, wq.data_ptr() if skip else None,
+                                                Co, Ci, wblocks, 0))
+                        wblocks += lib.hg_wino_pack_blocks(Co, Ci, int(bool(nf)), int(bool(nd)))
+                    for m_, t_ in ((PACK_FWD, wf), (PACK_DGRAD, wd)):
+                        t_.pack_src = (weakref.ref(p), m_, key)
                 up = lambda arr: torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).clone().to(device)
-                groups.append(dict(keys={key for key, _ in live[lo:hi]}, table=up((_PackItem * len(items))(*items)), n=len(items),
-                                   blocks=blocks, wn=len(witems), wblocks=wblocks,
+                groups.append(dict(keys={key for key, _ in live[lo:hi]}, table=up((_PackItem * len(items))(*items)) if items else None,
+                                   n=len(items), blocks=blocks, wn=len(witems), wblocks=wblocks,
                                    wtable=up((_WinoItem * len(witems))(*witems)) if witems else None))
-            plan = _multi[owner] = dict(sig=sig, bufs=bufs, groups=groups)
+            plan = _multi[owner] = dict(sig=sig, bufs=bufs, groups=groups, lazy=lazy)
         if not launch:
             return True
         _await_pack(owner, device)         # an asynchronous pack of the same buffers still in flight goes first
         _pack_events.pop(owner, None)
         events = []
+        for key in plan['lazy']:           # (weights changed: a direct operand packed on demand last step is stale again)
+            wf, wd, _ = plan['bufs'][key]
+            wf.direct_stale = wd.direct_stale = True
         for g in plan['groups']:
-            check(lib.hg_conv_pack_weights_multi(g['table'].data_ptr(), g['n'], g['blocks'], raw_stream(device)),
-                  'hg_conv_pack_weights_multi')
+            if g['table'] is not None:
+                check(lib.hg_conv_pack_weights_multi(g['table'].data_ptr(), g['n'], g['blocks'], raw_stream(device)),
+                      'hg_conv_pack_weights_multi')
             if g['wtable'] is not None:
                 check(lib.hg_wino_pack_weights_multi(g['wtable'].data_ptr(), g['wn'], g['wblocks'], raw_stream(device)),
                       'hg_wino_pack_weights_multi')
@@ -478,7 +512,7 @@ def conv_fwd_packed(x, wt, N, ksize, stride=1, iscale=None, oscale=None, bias=No
         out = torch.empty((B, N, _out_size(H, stride), _out_size(W, stride)), dtype=torch.float32, device=x.device)
         nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, stride, 0)
         ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
-        check(lib.hg_conv2d_fwd(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(iscale), _ptr(oscale), _ptr(bias),
+        check(lib.hg_conv2d_fwd(x.data_ptr(), _direct_operand(wt).data_ptr(), out.data_ptr(), _ptr(iscale), _ptr(oscale), _ptr(bias),
                                 B, K, N, H, W, ksize, stride, _ptr(ws), nb, _st(x)), 'hg_conv2d_fwd')
     return out
 
@@ -496,7 +530,7 @@ def conv_fwd_add_packed(x, wt, N, ksize, addend, bias=None, stride=1):
             raise ValueError(f'conv2d_add: addend {tuple(addend.shape)} does not match the output {tuple(out.shape)}')
         nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, stride, 0)
         ws = torch.empty(nb, dtype=torch.uint8, device=x.device) if nb else None
-        check(lib.hg_conv2d_fwd_add(x.data_ptr(), wt.data_ptr(), out.data_ptr(), addend.data_ptr(), _ptr(bias),
+        check(lib.hg_conv2d_fwd_add(x.data_ptr(), _direct_operand(wt).data_ptr(), out.data_ptr(), addend.data_ptr(), _ptr(bias),
                                     B, K, N, H, W, ksize, stride, _ptr(ws), nb, _st(x)), 'hg_conv2d_fwd_add')
     return out
 
@@ -526,7 +560,7 @@ def conv_dgrad_packed(g, wt, N, H, W, ksize, stride=1, iscale=None, oscale=None)
         gin = torch.empty((B, N, H, W), dtype=torch.float32, device=g.device)
         nb = lib.hg_conv2d_workspace_bytes(B, K, N, H, W, ksize, stride, 1)
         ws = torch.empty(nb, dtype=torch.uint8, device=g.device) if nb else None
-        check(lib.hg_conv2d_dgrad(g.data_ptr(), wt.data_ptr(), gin.data_ptr(), _ptr(iscale), _ptr(oscale),
+        check(lib.hg_conv2d_dgrad(g.data_ptr(), _direct_operand(wt).data_ptr(), gin.data_ptr(), _ptr(iscale), _ptr(oscale),
                                   B, K, N, H, W, ksize, stride, _ptr(ws), nb, _st(g)), 'hg_conv2d_dgrad')
     return gin
 

@@ -427,7 +427,8 @@ __global__ __launch_bounds__(256) void k_wino_reduce(const float *__restrict__ s
 // in both directions, since G J = P G for the 3x3 flip J and the row swap P).
 template <int TC, int KC>
 __device__ __forceinline__ void wino_pack_slot(const float *__restrict__ w, float *__restrict__ u, int Co, int Ci, int nblk,
-                                               int nch, int mode, int ch, int nb, int tid /* < NV * 64 */) {
+                                               int nch, int mode, int ch, int nb, int tid /* < NV * 64 */,
+                                               float *__restrict__ wsq = nullptr) {
   constexpr int NV = (KC / 2) * TC, NB = 32 * TC;
   int e, lane;
   if constexpr (NV >= 4) {
@@ -447,6 +448,12 @@ __device__ __forceinline__ void wino_pack_slot(const float *__restrict__ w, floa
     const float *p = w + (mode == HG_CONV_PACK_FWD ? ((size_t)n * Ci + k) : ((size_t)k * Ci + n)) * 9;
 #pragma unroll
     for (int q = 0; q < 9; ++q) g[q] = p[q];
+    if (wsq != nullptr && mode == HG_CONV_PACK_FWD) {   // every (co, ci) pair has exactly one slot per operand: written once
+      float q2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) q2 = fmaf(g[q], g[q], q2);   // (the tap order of pack_both_tile in hg_conv.hip)
+      wsq[(size_t)n * Ci + k] = q2;
+    }
   }
   // rows: G g (4 x 3), then columns: (G g) G^T (4 x 4)
   float gg[4][3];
@@ -493,13 +500,14 @@ __host__ __device__ inline PackGeom pack_geom(int Co, int Ci, int mode, int forc
   return g;
 }
 // pack block `local` (512 threads) of one (weight, mode)
-__device__ __forceinline__ void wino_pack_block(const float *w, float *u, int Co, int Ci, int mode, const PackGeom &g, int local) {
+__device__ __forceinline__ void wino_pack_block(const float *w, float *u, int Co, int Ci, int mode, const PackGeom &g, int local,
+                                                float *wsq = nullptr) {
   if (g.variant == 0) {
-    wino_pack_slot<2, 8>(w, u, Co, Ci, g.nblk, g.nch, mode, local % g.nch, local / g.nch, threadIdx.x);
+    wino_pack_slot<2, 8>(w, u, Co, Ci, g.nblk, g.nch, mode, local % g.nch, local / g.nch, threadIdx.x, wsq);
   } else {
     const int cg = (g.nch + 3) / 4;
     const int ch = (local % cg) * 4 + (threadIdx.x >> 7);
-    if (ch < g.nch) wino_pack_slot<1, 4>(w, u, Co, Ci, g.nblk, g.nch, mode, ch, local / cg, threadIdx.x & 127);
+    if (ch < g.nch) wino_pack_slot<1, 4>(w, u, Co, Ci, g.nblk, g.nch, mode, ch, local / cg, threadIdx.x & 127, wsq);
   }
 }
 __global__ __launch_bounds__(512) void k_wino_pack(const float *__restrict__ w, float *__restrict__ u, int Co, int Ci, int mode,
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(512) void k_wino_pack_multi(const hg_wino_pack_item
   const PackGeom gf = pack_geom(im.Co, im.Ci, HG_CONV_PACK_FWD, force_variant);
   const int bf = im.u_fwd ? gf.blocks : 0;
   if (local < bf) {
-    wino_pack_block(im.w, im.u_fwd, im.Co, im.Ci, HG_CONV_PACK_FWD, gf, local);
+    wino_pack_block(im.w, im.u_fwd, im.Co, im.Ci, HG_CONV_PACK_FWD, gf, local, im.wsq);
     return;
   }
   local -= bf;

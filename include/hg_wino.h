@@ -38,6 +38,9 @@ int hg_wino_pack_weights(const float *w, float *u, int32_t Co, int32_t Ci, int32
 typedef struct hg_wino_pack_item {
   const float *w;
   float *u_fwd, *u_dgrad;
+  /* optional (NULL: none; needs u_fwd): wsq[co][ci] = sum_taps W[co][ci][t]^2, as hg_pack_item.wsq of hg_conv.h (the weight
+   * factor of the demodulation coefficient) -- so that a weight whose direct operands nobody asks for needs no direct pack */
+  float *wsq;
   int32_t Co, Ci, block_begin, reserved;
 } hg_wino_pack_item;
 int32_t hg_wino_pack_blocks(int32_t Co, int32_t Ci, int32_t want_fwd, int32_t want_dgrad);
