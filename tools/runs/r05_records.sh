@@ -18,4 +18,19 @@ head -45 $OUT/step_timeline.txt
 if [ "${SKIP_PMC:-0}" != "1" ]; then
 timeout 500 bash tools/wino_pmc.sh gpurun_out/$TAG/pmc > $OUT/pmc.log 2>&1; grep -A3 "FETCH_SIZE\|WRITE_SIZE" $OUT/pmc/wino_pmc.txt | head -30
 fi
-timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-reference-eager --no-alt-precision > $OUT/bench_driver.json 2> $OUT/bench_driver.err; tail -c 400 $OUT/bench_driver.json
+timeout 120 tools/ubench/hist_fwd_loop > $OUT/ubench_hist_fwd_loop.txt 2>&1; head -2 $OUT/ubench_hist_fwd_loop.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err
+timeout 600 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+timeout 600 python bench.py --workload hist > $OUT/bench_hist.json 2> $OUT/bench_hist.err
+timeout 600 python bench.py --workload rehistogan --no-cpu-baseline > $OUT/bench_rehistogan.json 2> $OUT/bench_rehistogan.err
+timeout 900 python bench.py --workload c5 --no-cpu-baseline --no-reference-eager --no-alt-precision > $OUT/bench_c5.json 2> $OUT/bench_c5.err
+HG_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 12 --warmup 4 --no-roofline > $OUT/bench_n2_gloo.json 2> $OUT/bench_n2_gloo.err
+for f in bench_driver bench_default bench_hist bench_rehistogan bench_c5 bench_n2_gloo; do python - $OUT/$f.json <<'PY'
+import json,sys
+L=[l for l in open(sys.argv[1]).read().splitlines() if l.strip().startswith('{')]
+if not L: print(sys.argv[1].split('/')[-1], 'NO LINE'); sys.exit(0)
+d=json.loads(L[-1]); r=d.get('roofline') or {}
+print(sys.argv[1].split('/')[-1], 'lines', len(L), round(d['value'],1), round(d['ms_per_step'],3), d.get('n_gpus'), r.get('frac'), r.get('traffic'))
+PY
+done
