@@ -54,6 +54,7 @@ struct WinoArgs {
   int ksplit;
   float *slab;
   int blocks, total_tiles;  // tiles per K split, tiles of the launch (= blocks * ksplit)
+  int xcd;                  // 1: the channel blocks of a block tile run on ONE XCD (see tile_setup)
 };
 
 // accumulator row of register r (v_mfma_f32_32x32x2_f32: D[i][j], j = lane & 31, i = row(r, lane >> 5))
@@ -95,14 +96,23 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   const float *inblk = a.in;
   unsigned vo[4], so = kOOB, uo[2];
   bool c0bad = false, c3bad = false, sh1 = false;
-  // tile -> (K split, block tile, channel block); the channel block varies fastest: the workgroups that read the same
-  // input tiles are neighbours in dispatch order (their second read hits the Infinity Cache), and with >= 8 channel blocks
-  // every XCD only ever sees an eighth of U
+  // tile -> (K split, block tile, channel block).  With >= 8 channel blocks the channel block varies fastest: every XCD only
+  // ever sees an eighth of U, and the workgroups that read the same input tiles are neighbours in dispatch order (their
+  // second read hits the Infinity Cache).  With 2 or 4 channel blocks (a.xcd) the blocks of one tile are dispatched eight
+  // apart instead -- the SAME XCD, the same moment: fabric reads of the 256 -> 128 @64^2 launch 721 -> 411 MB (FETCH_SIZE,
+  // calibrated: profiles/r05_fetch_calibration.txt) against 134 MB of input + 2 MB of U; the launch time does not change
+  // (the kernel is not bound by the fabric), the traffic does
   auto tile_setup = [&](int L) __attribute__((always_inline)) {
     int pt = L % a.blocks;
     zs = L / a.blocks;
-    nb = pt % a.nblk;
-    pt /= a.nblk;
+    if (a.xcd) {     // work item L runs on XCD L % 8 (round-robin dispatch, grid a multiple of 8): tile = 8 * group + XCD
+      const int q = pt & 7, r = pt >> 3;
+      nb = r % a.nblk;
+      pt = (r / a.nblk) * 8 + q;
+    } else {
+      nb = pt % a.nblk;
+      pt /= a.nblk;
+    }
     bx = pt % a.bt_x;
     pt /= a.bt_x;
     by = pt % a.bt_y;
@@ -551,6 +561,7 @@ struct WinoWgArgs {
   int lcg, lrg;            // log2 of the column / row groups of a map (tiles_w >> lPW, tiles_h >> lPH)
   int Np, Kp;              // slab extents (multiples of 64)
   int xtiles, total_blocks;  // (n, k) tiles, tiles x splits
+  int xcd;                   // 1: all (n, k) tiles of a pixel split run on ONE XCD
 };
 
 constexpr int WG_P = 68;                   // LDS row pitch (floats) of a [position][tile] row of 64 channels
@@ -562,7 +573,19 @@ __global__ __launch_bounds__(512) void k_wino_wgrad(const WinoWgArgs a) {
   const int lm = lane & 31, lk = lane >> 5;
   const int H = a.H, W = a.W, K = a.K, N = a.N, HW = H * W;
   for (int L = blockIdx.x; L < a.total_blocks; L += gridDim.x) {    // persistent, as k_wino
-  const int bxy = L % a.xtiles, sp = L / a.xtiles;
+  // Work item L runs on XCD L % 8.  a.xcd: split = 8 * group + XCD and the (n, k) tiles of a split follow each other eight
+  // apart -- every block that reads a pixel range sits behind the same L2, so `in` and `gout` cross the fabric once instead
+  // of once per n tile / k tile (the old order, (n, k) tile fastest, gave each XCD ONE channel tile and all the pixels:
+  // fabric reads 1917 MB at 256 -> 128 @64^2 against 201 MB of operands; now 201.5 MB).  Same slabs, same sums: bit-identical.
+  int bxy, sp;
+  if (a.xcd) {
+    const int q = L & 7, r = L >> 3;
+    bxy = r % a.xtiles;
+    sp = (r / a.xtiles) * 8 + q;
+  } else {
+    bxy = L % a.xtiles;
+    sp = L / a.xtiles;
+  }
   const int k0 = (bxy % a.ktiles) * 64, n0 = (bxy / a.ktiles) * 64;
 
   // ---- transform role: tile t of the chunk pattern, channel ch of the block's 64 (input channel k0 + ch / gradient
@@ -1022,6 +1045,8 @@ int hg_wino_conv2d(const float *in, const float *u, float *out, const float *isc
   a.tiles_w = p.tiles_w; a.tiles_h = p.tiles_h; a.bt_x = p.bt_x; a.bt_y = p.bt_y;
   a.ksplit = p.ksplit; a.slab = (float *)workspace;
   a.blocks = (int)p.blocks; a.total_tiles = (int)(p.blocks * p.ksplit);
+  static const int xcd = getenv("HG_WINO_XCD") ? atoi(getenv("HG_WINO_XCD")) : 1;
+  a.xcd = xcd && p.nblk > 1 && p.nblk < 8 && (p.blocks / p.nblk) % 8 == 0;
   hipStream_t st = (hipStream_t)stream;
   const bool fe = iscale != nullptr;
   int rc = p.variant == 0 ? launch_wino<2, 2, 8>(a, p, fe, st) : launch_wino<1, 4, 4>(a, p, fe, st);
@@ -1076,6 +1101,8 @@ int hg_wino_wgrad(const float *in, const float *gout, float *gw, int32_t B, int3
     attr = true;
   }
   a.xtiles = p.ktiles * p.ntiles; a.total_blocks = a.xtiles * p.splits;
+  static const int xcd = getenv("HG_WINO_XCD") ? atoi(getenv("HG_WINO_XCD")) : 1;
+  a.xcd = xcd && p.splits % 8 == 0;
   static const int persist = getenv("HG_WINO_PERSIST") ? atoi(getenv("HG_WINO_PERSIST")) : 1;
   const int grid = persist && a.total_blocks > num_cus() ? num_cus() : a.total_blocks;
   hipLaunchKernelGGL(k_wino_wgrad, dim3((unsigned)grid), dim3(512), lds, st, a);

@@ -10,6 +10,22 @@ dev = torch.device('cuda:0')
 B = 32
 it = int(os.environ.get('HG_ONE_ITERS', 4))
 ONLY = os.environ.get('HG_PMC_ONLY', '')      # 'roofline': bench.py's roofline launch alone (per-launch FETCH_SIZE / WRITE_SIZE)
+# HG_PMC_WARM_MS: that many ms of library GEMMs first (other kernel names).  A kernel trace that starts on an idle GPU shows a
+# power-management transient in its first ~60 launches (367 -> 407 -> 324 us and still falling at 256 -> 128 @64^2; a GEMM
+# warm-up only moves the transient: 421 -> 338), not the steady state bench.py times after its training steps: the traces that
+# are compared with bench.py run 600 launches instead (tools/wino_pmc.sh)
+WARM = float(os.environ.get('HG_PMC_WARM_MS', 0))
+if WARM > 0:
+    m = torch.randn(4096, 4096, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    while True:
+        for _ in range(20):
+            m @ m
+        e1.record()
+        e1.synchronize()
+        if e0.elapsed_time(e1) >= WARM:
+            break
 FWD = ((256, 128, 64),) if ONLY == 'roofline' else ((256, 128, 64), (512, 512, 16))
 WG = ((256, 128, 64),) if ONLY == 'roofline' else ((512, 512, 16), (128, 128, 64))
 if ONLY == 'leading':

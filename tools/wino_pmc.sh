@@ -19,9 +19,9 @@ mkdir -p "$OUT/roof"
 runr fetch FETCH_SIZE
 runr write WRITE_SIZE
 python tools/pmc_summary.py "$OUT/roof" "k_wino" > "$OUT/wino_roofline_traffic.txt" 2>&1
-(cd /tmp && HG_PMC_ONLY=roofline HG_ONE_ITERS=60 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/roof/trace" -o t -- python "$ROOT/tools/wino_pmc.py" > "$ROOT/$OUT/roof_trace.log" 2>&1)
+(cd /tmp && HG_PMC_ONLY=roofline HG_ONE_ITERS=600 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/roof/trace" -o t -- python "$ROOT/tools/wino_pmc.py" > "$ROOT/$OUT/roof_trace.log" 2>&1)
 cp "$OUT"/roof/trace/*kernel_stats.csv "$OUT/wino_roofline_kernel_stats.csv" 2>/dev/null
-(cd /tmp && HG_PMC_ONLY=leading HG_ONE_ITERS=60 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/lead/trace" -o t -- python "$ROOT/tools/wino_pmc.py" > "$ROOT/$OUT/lead_trace.log" 2>&1)
+(cd /tmp && HG_PMC_ONLY=leading HG_ONE_ITERS=600 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/lead/trace" -o t -- python "$ROOT/tools/wino_pmc.py" > "$ROOT/$OUT/lead_trace.log" 2>&1)
 cp "$OUT"/lead/trace/*kernel_stats.csv "$OUT/wino_leading_kernel_stats.csv" 2>/dev/null
 (cd /tmp && HG_ONE_ITERS=40 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace" -o t -- python "$ROOT/tools/wino_pmc.py" > "$ROOT/$OUT/trace.log" 2>&1)
 find "$OUT" -name "*.csv" -size +300k -delete
