@@ -298,12 +298,13 @@ def _direct_operand(wt):
     if getattr(wt, 'direct_stale', False):
         ref, mode, key = wt.pack_src
         p = ref()
-        if p is not None:
-            Co, Ci, k, _ = p.shape
-            with on_device(p.device):
-                check(lib.hg_conv_pack_weights(p.data_ptr(), wt.data_ptr(), Co, Ci, k, mode, _st(p)), 'hg_conv_pack_weights')
-            wt.direct_stale = False
-            _direct_needed.add(key)
+        if p is None:       # (an operand outliving its weight: nothing to pack from -- never hand a stale buffer to a launch)
+            raise RuntimeError('direct convolution operand requested for a weight that no longer exists')
+        Co, Ci, k, _ = p.shape
+        with on_device(p.device):
+            check(lib.hg_conv_pack_weights(p.data_ptr(), wt.data_ptr(), Co, Ci, k, mode, _st(p)), 'hg_conv_pack_weights')
+        wt.direct_stale = False
+        _direct_needed.add(key)
     return wt
 
 

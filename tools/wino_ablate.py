@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Times hg_wino_conv2d on two layers for the current library (HG_LIB_TAG): used with the HG_WINO_DBG ablation builds
-(results of those builds are garbage by construction; only the times mean anything)."""
+"""Times hg_wino_conv2d on four layers for the current library (HG_LIB_TAG): used with the HG_WINO_DBG ablation builds
+(results of those builds are garbage by construction; only the times mean anything).  The -DHG_WINO_DBG=... switches were
+removed from hg_wino.hip after the measurement (profiles/r05_wino_ablation.txt); they are in the history at commit f419444
+(`git show f419444:histogan_amd/csrc/hg_wino.hip`)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
