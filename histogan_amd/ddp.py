@@ -9,6 +9,8 @@ The reference is single-GPU (histoGAN.py:242,268); these semantics are new (SURV
   large collectives use all 7 links per GPU, where many small per-tensor ones would be latency-bound;
 * the D-gradient all-reduce is launched asynchronously right after the D backward and overlaps the
   generator forward of the G phase (which does not touch D); it is waited for before D_opt.step();
+* that generator forward runs on a second stream beside the D phase whenever every rank owns its GPU
+  (ranks_share_a_device: two processes on one GPU oversubscribe its hardware queues, DESIGN.md section 9);
 * scalar state that steers control flow (NaN flag, pl_mean) is all-reduced so ranks never diverge.
 """
 import os
@@ -31,6 +33,46 @@ def world_size():
 
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _device_identity(device):
+    """(host, physical device) of this rank: PCI address where torch exposes it (two ranks can both call their GPU 'cuda:0')."""
+    import socket
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return (socket.gethostname(), 'cpu', os.getpid())
+    pr = torch.cuda.get_device_properties(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    # everything that can tell two GPUs apart, whichever of it this torch / driver fills in: two ranks on ONE GPU agree on all
+    # of it, two ranks on different GPUs differ in at least one entry
+    ident = (str(getattr(pr, 'uuid', '')), getattr(pr, 'pci_domain_id', -1), getattr(pr, 'pci_bus_id', -1),
+             getattr(pr, 'pci_device_id', -1), os.environ.get('HIP_VISIBLE_DEVICES', ''), os.environ.get('CUDA_VISIBLE_DEVICES', ''),
+             os.environ.get('ROCR_VISIBLE_DEVICES', ''), index)
+    return (socket.gethostname(), 'cuda', str(ident))
+
+
+def _any_shared(identities):
+    return len(set(identities)) < len(identities)
+
+
+_shared = {}
+
+
+def ranks_share_a_device(device):
+    """True when two ranks of the process group sit on ONE physical GPU (the two-gloo-ranks-on-one-GPU test set-up; never on
+    a node run as one process per GPU).  A COLLECTIVE on first use per device (all_gather_object): every rank must reach it
+    at the same point -- the trainer asks in its first data-parallel step.  Matters because a shared GPU carries the hardware
+    queues of both processes: with more than ~4 in total the step's cross-stream waits cost scheduler time slices
+    (3752 ms per step with 2 x 4 queues, 272 ms with 2 x 2)."""
+    key = str(device)
+    if key not in _shared:
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            _shared[key] = False
+        else:
+            seen = [None] * dist.get_world_size()
+            dist.all_gather_object(seen, _device_identity(device))
+            _shared[key] = _any_shared([tuple(x) if isinstance(x, (list, tuple)) else x for x in seen])
+    return _shared[key]
 
 
 def broadcast_flat(flat, src=0):

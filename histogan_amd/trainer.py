@@ -50,7 +50,7 @@ from .optim import DiffGrad, FlatParams, ema_update
 
 EPS = 1e-8
 EXTS = ['jpg', 'png']
-G_OVERLAP_DDP = os.environ.get('HG_G_OVERLAP_DDP', '0') == '1'   # the same under data parallelism (see _device_step)
+G_OVERLAP_DDP = os.environ.get('HG_G_OVERLAP_DDP', 'auto')   # the same under data parallelism: auto | 1 | 0 (see _device_step)
 G_OVERLAP = os.environ.get('HG_G_OVERLAP', '1') != '0'   # G-phase generator forward on a second stream beside the D phase
 G_STREAM_PRIO = int(os.environ.get('HG_G_STREAM_PRIO', '0'))   # HIP priority of that stream (0 normal, -1 high)
 H_SIDE = os.environ.get('HG_H_SIDE', '1') != '0'               # D phase: histogram vectorizer on a second stream beside S
@@ -614,12 +614,19 @@ class Trainer():
                 noise = self.rng.image_noise(batch_size, image_size)
             return noise, hist_batch, w_styles, h_w_space, GAN.G(w_styles, h_w_space, noise)
 
-        # Under data parallelism the second-stream forward is OPT-IN (HG_G_OVERLAP_DDP=1).  Nothing it touches depends on
-        # the D-gradient all-reduce (RCCL's own stream; waited for by D's optimizer step only), but the one multi-rank set-up
-        # that can be measured here -- two gloo ranks sharing a GPU -- runs 1.73 s per step with it and 0.26 s without
-        # (profiles/r04_ddp_gloo_knobs.json: seven streams per process on one device), so the default stays round 3's
-        # until a multi-GPU node says otherwise.
-        overlap_g = G_OVERLAP and acc == 1 and (G_OVERLAP_DDP or not ddp.is_dist())
+        # Under data parallelism (HG_G_OVERLAP_DDP = auto) the second-stream forward is used whenever every rank owns its GPU.
+        # Nothing it touches depends on the D-gradient all-reduce (RCCL's own stream; waited for by D's optimizer step only):
+        # one rank's view of a node (RCCL, world size 1 forced) runs 39.6 ms per step with it, 40.0 without.  It is switched
+        # off when ranks SHARE a device -- the two-gloo-ranks-on-one-GPU test set-up ran 2.8-4.2 s per step with it and 0.26 s
+        # without, and that follows the hardware-queue count the two processes put on the one GPU, not the step: with
+        # GPU_MAX_HW_QUEUES=2 per process the same step takes 0.27 s (profiles/r05_ddp_overlap_shared_gpu.json).
+        if not ddp.is_dist():
+            ddp_ok = True
+        elif G_OVERLAP_DDP in ('0', '1'):
+            ddp_ok = G_OVERLAP_DDP == '1'
+        else:
+            ddp_ok = not ddp.ranks_share_a_device(dev)        # (collective on first use: every rank is in its first step here)
+        overlap_g = G_OVERLAP and acc == 1 and ddp_ok
         if overlap_g and not getattr(self, '_warn_off', False):
             # parameters live on the default stream, part of the graph now runs on another one: the engine's stream
             # hand-over is intended

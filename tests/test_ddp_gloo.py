@@ -62,6 +62,14 @@ def _worker(rank, world, port, q):
         rb.finish()
         assert ddp.all_reduce_scalar(float(rank), 'mean') == pytest.approx(0.5)
         assert ddp.all_reduce_scalar(float(rank), 'max') == 1.0
+        # shared-device detection (a collective): two CPU ranks are two processes -> nothing shared; a faked common identity is
+        assert ddp.ranks_share_a_device('cpu') is False
+        real = ddp._device_identity
+        ddp._device_identity = lambda device: ('host', 'cuda', 'the one GPU')
+        try:
+            assert ddp.ranks_share_a_device('cuda:0') is True          # (first use for this key: gathers the faked identities)
+        finally:
+            ddp._device_identity = real
         q.put((rank, 'ok'))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
@@ -92,6 +100,9 @@ def test_single_process_is_identity():
     assert torch.all(flat.grad == 2.0)
     assert ddp.world_size() == 1 and ddp.rank() == 0
     assert ddp.all_reduce_scalar(3.5) == 3.5
+    assert ddp.ranks_share_a_device('cpu') is False                     # no process group: no collective, nothing shared
+    assert ddp._any_shared([('a', 'cuda', '0'), ('a', 'cuda', '1'), ('b', 'cuda', '0')]) is False
+    assert ddp._any_shared([('a', 'cuda', '0'), ('a', 'cuda', '0')]) is True
 
 
 def test_flatparams_gather_with_directly_written_slots():
