@@ -149,7 +149,9 @@ def test_c5_full_width_discriminator_and_penalty_match_fp64_oracle(gpu_device):
         pytest.skip('needs ~80 GB of device memory')
     torch.manual_seed(77)
     dev = gpu_device
-    D = Discriminator(1024, network_capacity=16, attn_layers=[3, 4]).to(dev)
+    with torch.device(dev):       # 1.45 G parameters drawn on the GPU (on the CPU the initialisation alone takes most of a minute)
+        D = Discriminator(1024, network_capacity=16, attn_layers=[3, 4])
+    D = D.to(dev)
     with torch.no_grad():
         for k, v in D.named_parameters():
             if k.endswith('.g'):
@@ -170,9 +172,12 @@ def test_c5_full_width_discriminator_and_penalty_match_fp64_oracle(gpu_device):
     def oracle(dt):
         sd = {k: v.detach().to(dt).clone().requires_grad_(True) for k, v in D.state_dict().items()}
         xc = img.to(dt).clone().requires_grad_(True)
-        lo = N.discriminator(sd, xc, len(D.blocks))
-        gpo = N.gradient_penalty(xc, lo)
-        gr = torch.autograd.grad(torch.relu(1 + lo).mean() + gpo, [sd[n] for n in names])
+        # aten's native convolution (unfold + library GEMM) instead of MIOpen: on a fresh box MIOpen compiles a kernel per
+        # convolution configuration and direction at run time -- most of this test's two minutes
+        with torch.backends.cudnn.flags(enabled=False):
+            lo = N.discriminator(sd, xc, len(D.blocks))
+            gpo = N.gradient_penalty(xc, lo)
+            gr = torch.autograd.grad(torch.relu(1 + lo).mean() + gpo, [sd[n] for n in names])
         out = lo.detach().clone(), float(gpo), [g.detach() for g in gr]
         del sd, xc, lo, gpo, gr
         torch.cuda.empty_cache()
