@@ -70,7 +70,12 @@ def ranks_share_a_device(device):
             _shared[key] = False
         else:
             seen = [None] * dist.get_world_size()
-            dist.all_gather_object(seen, _device_identity(device))
+            d = torch.device(device)
+            if d.type == 'cuda' and torch.cuda.is_available():   # (RCCL moves the pickled object through the CURRENT device: make it this rank's)
+                with torch.cuda.device(d):
+                    dist.all_gather_object(seen, _device_identity(d))
+            else:
+                dist.all_gather_object(seen, _device_identity(d))
             _shared[key] = _any_shared([tuple(x) if isinstance(x, (list, tuple)) else x for x in seen])
     return _shared[key]
 
