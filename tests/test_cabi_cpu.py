@@ -230,3 +230,27 @@ def test_wino_host_logic(L):
     assert lib.hg_wino_conv2d(None, None, None, None, None, None, None, None, 0, 0.0, None, 1, 8, 8, 4, 4, None, 0, None) < 0
     assert lib.hg_wino_wgrad(None, None, None, 1, 8, 8, 4, 4, None, 0, None) < 0
     assert lib.hg_wino_pack_weights(None, None, 8, 8, 0, None) < 0
+
+
+def test_torgb_host_logic(L):
+    """hg_torgb_* (include/hg_nets.h), host side only: the adjoint's workspace follows the block geometry (<= 8 pixel blocks per
+    image, (1 + C) partial sums per block and channel), unsupported shapes and bad arguments are refused before any launch."""
+    import ctypes
+    lib = L.lib
+    # 256^2 map: 16 384 pixel quads, 64 per block -> 256 chunks -> 8 pixel blocks per image
+    assert lib.hg_torgb_bwd_workspace_bytes(32, 32, 3, 256 * 256) == 32 * 8 * 32 * (1 + 3) * 4
+    # 4x4 map: 4 quads -> one block of 4 quads x 64 channel groups
+    assert lib.hg_torgb_bwd_workspace_bytes(32, 2048, 3, 16) == 32 * 1 * 2048 * (1 + 3) * 4
+    assert lib.hg_torgb_bwd_workspace_bytes(2, 64, 4, 64 * 64) == 2 * 8 * 64 * (1 + 4) * 4        # rgba
+    assert lib.hg_torgb_bwd_workspace_bytes(32, 32, 5, 256 * 256) == 0 and lib.hg_torgb_bwd_workspace_bytes(32, 32, 3, 6) == 0
+    p = ctypes.c_void_p(4096)          # never dereferenced: every call below returns before a launch
+    einval = lib.hg_torgb_fwd(None, None, None, None, None, 1, 8, 3, 16, None)
+    unsup = lib.hg_torgb_fwd(p, p, p, None, p, 1, 8, 5, 16, None)
+    assert einval < 0 and unsup < 0 and einval != unsup
+    assert lib.hg_torgb_fwd(p, p, p, None, p, 1, 8, 3, 18, None) == unsup                         # pixels not a multiple of 4
+    assert lib.hg_torgb_fwd(p, p, p, None, p, 1, 8192, 3, 16, None) == unsup                      # 3 x 8192 weights exceed the LDS plan
+    assert lib.hg_torgb_bwd(p, p, p, p, p, None, p, 1, 8, 3, 16, p, 1 << 20, None) == einval      # style without its gradient
+    ws = lib.hg_torgb_bwd_workspace_bytes(1, 8, 3, 16)
+    short = lib.hg_torgb_bwd(p, p, p, p, p, p, p, 1, 8, 3, 16, p, ws - 1, None)
+    assert short < 0 and short not in (einval, unsup)
+
