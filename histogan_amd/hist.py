@@ -148,39 +148,21 @@ class RGBuvHistFunction(torch.autograd.Function):
         return gx, None, None
 
 
-_CPU_REDIRECT_WARNED = False
-
-
 def run_block(x, cfg, device, what, pre_relu=False):
     """forward() of the drop-in histogram modules: resolves the module's `device` argument the way the reference does
     ('cuda', 'cpu', an ordinal, a torch.device).
 
-    device='cpu' is what the reference's Dataset uses inside DataLoader workers (histoGAN/histoGAN.py:263-266, 296-302).
-    This build has no CPU kernels: such a call is REDIRECTED -- computed on the current GPU, result returned on the CPU
-    (the reference contract: output lives on `device`), with one warning.  Inside a forked DataLoader worker the GPU
-    must not be touched at all (HIP state does not survive fork): there the call raises with a pointer to the
-    restructured data source (histogan_amd/data.FolderData computes and caches the target histograms on the GPU)."""
-    global _CPU_REDIRECT_WARNED
+    device='cpu' is what the reference's Dataset uses inside forked DataLoader workers (histoGAN/histoGAN.py:263-266,
+    296-302): that call runs `hist_cpu.hist_cpu` -- PyTorch CPU ops only, no HIP call, no GPU memory (SURVEY.md
+    section 8b: the replacement must not touch the GPU when device='cpu').  It is a separate implementation for that
+    contract, not a fallback: a GPU module never takes it, and the HIP functions keep refusing CPU tensors."""
     dev = torch.device('cuda', device) if isinstance(device, int) else torch.device(device)
-    to_cpu = dev.type != 'cuda'
-    if to_cpu:
-        import torch.utils.data as tud
-        if tud.get_worker_info() is not None:
-            raise RuntimeError(f"{what}(device={device!r}) inside a DataLoader worker: the MI355X-native build has no CPU "
-                               "kernels and a forked worker must not touch the GPU; use histogan_amd.data.FolderData "
-                               "(Trainer.set_data_src), which computes the target histograms on the GPU and caches them")
-        if not torch.cuda.is_available():
-            raise RuntimeError(f"{what}(device={device!r}): the MI355X-native build has no CPU path and no GPU is visible")
-        if not _CPU_REDIRECT_WARNED:
-            import warnings
-            warnings.warn(f"{what}(device={device!r}): no CPU kernels in the MI355X-native build; computing on "
-                          f"cuda:{torch.cuda.current_device()} and returning the histogram on the CPU")
-            _CPU_REDIRECT_WARNED = True
-        dev = torch.device('cuda', torch.cuda.current_device())
+    if dev.type != 'cuda':
+        from .hist_cpu import hist_cpu
+        return hist_cpu(x if not x.is_cuda else x.cpu(), cfg, pre_relu)
     if not x.is_cuda:
         x = x.to(dev)
-    out = rgbuv_hist(x, cfg, pre_relu)
-    return out.cpu() if to_cpu else out
+    return rgbuv_hist(x, cfg, pre_relu)
 
 
 def rgbuv_hist(x, cfg, pre_relu=False):

@@ -582,6 +582,8 @@ class Trainer():
         GAN = self.GAN
         dev = self.device
         zero = lambda: torch.zeros((), device=dev)
+        mark = self._mark
+        mark('start')
         total_disc_loss, total_gen_loss, total_hist_loss = zero(), zero(), zero()
         gp_val, q_val, pl_len = zero(), zero(), None
 
@@ -659,6 +661,7 @@ class Trainer():
                     w_styles, h_w_space = w_and_hw_static('tt_d', hist_batch)
                     noise = self.rng.image_noise(batch_size, image_size)
                 generated_images = GAN.G(w_styles, h_w_space, noise)
+            mark('d_phase_g_forward')
             if overlap_g:
                 # The generator forward of the G phase depends on nothing the D phase produces (same generator
                 # weights, own latents): it runs on a second stream beside the discriminator's forward / backward --
@@ -681,6 +684,7 @@ class Trainer():
                 both_output, both_q_loss = Disc(_cat_batches(aug(generated_images, True), aug(image_batch)))
                 fake_output, real_output = both_output[:batch_size], both_output[batch_size:]
                 fake_q_loss = real_q_loss = both_q_loss * 0.5
+            mark('d_forward')
             divergence = (F.relu(1 + real_output) + F.relu(1 - fake_output)).mean()
             quantize_loss = (fake_q_loss + real_q_loss).mean()
             q_val = quantize_loss.detach()
@@ -691,6 +695,7 @@ class Trainer():
                 disc_loss = disc_loss + gp
             disc_loss = disc_loss / acc
             disc_loss.backward()
+            mark('d_backward')
             total_disc_loss += divergence.detach() / acc
         GAN._reduce_d.start()          # async all-reduce of D grads; overlaps the G forward below
 
@@ -711,6 +716,7 @@ class Trainer():
             GAN._reduce_g()
             GAN.G_opt.step()
         prepack_async(GAN._flat_g.data)        # next step's generator operands, under the head of its forward
+        mark('g_optimizer')
 
         return torch.stack([total_disc_loss, total_gen_loss, total_hist_loss, gp_val.reshape(()),
                             q_val.reshape(()), pl_len if pl_len is not None else zero()]).double()
@@ -744,6 +750,7 @@ class Trainer():
             if not d_updated:
                 update_d()
                 d_updated = True
+            self._mark('g_forward_joined_d_updated')
             fake_output, _ = Disc(aug(generated_images))
             generated_histograms = self.histBlock(generated_images, pre_relu=True)   # == histBlock(F.relu(.)), reference :955
             histogram_loss = hellinger_loss(hist_batch, generated_histograms, alpha)
@@ -762,7 +769,9 @@ class Trainer():
                     if not bool(torch.isnan(pl_loss)):
                         gen_loss = gen_loss + pl_loss
             gen_loss = gen_loss / acc
+            self._mark('g_phase_d_forward_hist_loss')
             gen_loss.backward()
+            self._mark('g_backward')
             total_gen_loss = total_gen_loss + loss.detach() / acc
             total_hist_loss = total_hist_loss + histogram_loss.detach() / acc
         return total_gen_loss, total_hist_loss, pl_len
@@ -841,6 +850,14 @@ class Trainer():
             self.evaluate(floor(self.steps / 1000))
         self.steps += 1
         self.av = None
+
+    def _mark(self, name):
+        """Phase marker of the step on the CURRENT stream (tools/phase_probe.py sets `phase_events = []`; None: no-op)."""
+        pe = self.__dict__.get('phase_events')
+        if pe is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            pe.append((name, ev, perf_counter()))
 
     # ---- deferred statistics -----------------------------------------------------------------
     def _host_buffer(self):

@@ -23,7 +23,8 @@ class RGBuvHistBlock(nn.Module):
     strided samples); method in {'thresholding', 'RBF', 'inverse-quadratic'}; sigma of the
     RBF / inverse-quadratic kernel; intensity_scale (I_y weighting); hist_boundary (default
     [-3, 3], sorted in place like the reference); green_only (only the log(g/r), log(g/b) plane).
-    `device`: a GPU; 'cpu' is redirected to the current GPU with the result returned on the CPU (histogan_amd.hist.run_block).
+    `device`: a GPU runs the HIP kernels; 'cpu' (the reference Dataset's use inside DataLoader workers) runs
+    histogan_amd/hist_cpu.py -- PyTorch CPU ops, no HIP call (histogan_amd.hist.run_block).
     """
     super(RGBuvHistBlock, self).__init__()
     self.h = h

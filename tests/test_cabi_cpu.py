@@ -94,12 +94,14 @@ def test_null_pointers_rejected_before_any_launch(L):
 
 
 def test_cpu_tensor_is_refused_loudly(L):
+    """The HIP path has no CPU fallback: its autograd Functions refuse CPU tensors.  (A module built with device='cpu' --
+    the reference's Dataset use -- is a separate, HIP-free implementation: tests/test_hist_cpu_path.py.)"""
     import torch
-    from histogram_classes.RGBuvHistBlock import RGBuvHistBlock
-    if torch.cuda.is_available():
-        pytest.skip('with a GPU present device="cpu" is redirected to it (tests/test_hist_gpu.py covers that)')
-    with pytest.raises(RuntimeError):
-        RGBuvHistBlock(device='cpu')(torch.rand(1, 3, 8, 8))
+    from histogan_amd.hist import HistConfig, HellingerFunction, RGBuvHistFunction
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        RGBuvHistFunction.apply(torch.rand(1, 3, 8, 8), HistConfig(h=16), False)
+    with pytest.raises(RuntimeError, match='no CPU implementation'):
+        HellingerFunction.apply(torch.rand(1, 3, 4, 4), torch.rand(1, 3, 4, 4), 1.0)
 
 
 def test_pack_cache_registration_is_additive_and_weak():

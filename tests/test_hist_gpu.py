@@ -126,9 +126,9 @@ def test_module_surface_matches_reference_contract(gpu_device):
     with pytest.raises(Exception, match='Wrong resizing method'):
         RGBuvHistBlock(h=16, insz=8, resizing='nearest')(x.to(gpu_device))
     RGBuvHistBlock(h=16, insz=64, resizing='nearest')(x.to(gpu_device))    # not reached when no resize is needed (:80-93)
-    with pytest.warns(UserWarning, match='no CPU kernels'):                  # device='cpu': computed on the GPU, returned on the CPU
-        out_cpu = RGBuvHistBlock(h=16, device='cpu')(x)
+    out_cpu = RGBuvHistBlock(h=16, device='cpu')(x)                         # device='cpu': the HIP-free CPU implementation
     assert out_cpu.device.type == 'cpu' and relmax(out_cpu.numpy(), ref) <= FWD_TOL
+    assert RGBuvHistBlock(h=16, device='cpu')(x.to(gpu_device)).device.type == 'cpu'
     # sums to one over all planes; one plane when green_only
     s = RGBuvHistBlock(h=16)(x.to(gpu_device)).sum(dim=(1, 2, 3))
     assert torch.allclose(s, torch.ones_like(s), atol=1e-5)
