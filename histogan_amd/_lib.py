@@ -84,6 +84,11 @@ def _load():
     lib.hg_torgb_bwd_workspace_bytes.argtypes = [i32, i32, i32, i32]
     lib.hg_torgb_bwd.restype = ctypes.c_int
     lib.hg_torgb_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]
+    lib.hg_gstage_bwd_workspace_bytes.restype = sz
+    lib.hg_gstage_bwd_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    lib.hg_gstage_bwd.restype = ctypes.c_int
+    lib.hg_gstage_bwd.argtypes = [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32,
+                                  vp, sz, vp]
     lib.hg_channel_sum.restype = ctypes.c_int
     lib.hg_channel_sum.argtypes = [vp, vp, i32, i32, i32, vp, sz, vp]
     lib.hg_demod_noise_lrelu_fwd.restype = ctypes.c_int
@@ -211,7 +216,7 @@ EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg
            'hg_grouped_linear_bwd_input', 'hg_grouped_linear_bwd_params',
            'hg_wino_supported', 'hg_wino_packed_elems', 'hg_wino_pack_weights', 'hg_wino_pack_blocks', 'hg_wino_pack_weights_multi', 'hg_wino_workspace_bytes', 'hg_wino_conv2d',
            'hg_wino_wgrad_supported', 'hg_wino_wgrad_workspace_bytes', 'hg_wino_wgrad',
-           'hg_torgb_fwd', 'hg_torgb_bwd_workspace_bytes', 'hg_torgb_bwd')
+           'hg_torgb_fwd', 'hg_torgb_bwd_workspace_bytes', 'hg_torgb_bwd', 'hg_gstage_bwd_workspace_bytes', 'hg_gstage_bwd')
 
 
 class HgError(RuntimeError):

@@ -618,6 +618,21 @@ def register_grad_slots(flat):
         off += n
 
 
+def grad_slot(w):
+    """(slot view, owner FlatParams) of a registered convolution weight whose gradient may be written directly right now
+    (between zero_grad() and gather(), plain backward), or None."""
+    if not SIDE_WGRAD or torch.is_grad_enabled():
+        return None
+    ent = _slots.get((w.data_ptr(), tuple(w.shape)))
+    if ent is None:
+        return None
+    off, n, ref = ent
+    flat = ref()
+    if flat is None or not getattr(flat, 'direct_ok', False):
+        return None
+    return flat.grad[off:off + n].view(w.shape), flat
+
+
 def side_stream(device):
     st = _side_streams.get(device.index)
     if st is None:

@@ -48,6 +48,7 @@ def _noise_t(inoise):
 
 
 STYLES_AHEAD = os.environ.get('HG_STYLES_AHEAD', '1') != '0'
+PHASE_HOOK = None     # tools/phase_probe.py: called with a phase name at points inside the networks (None: no-op)
 _aux_streams = {}
 
 
@@ -229,6 +230,14 @@ class Generator(nn.Module):
                 styles.record_stream(aux)
             else:
                 t = ops.grouped_linear(xs, layers, groups)
+            if PHASE_HOOK is not None:
+                PHASE_HOOK('g_styles_projected', False)
+            if input_noise is not None and input_noise.dim() == 4:
+                from . import gfused
+                nzt = _noise_t(input_noise)
+                if gfused.supported(self, t, nzt):
+                    # training: the whole network as ONE autograd node with a hand-written backward (gfused.py)
+                    return gfused.generator_train(self, t, nzt)
             for i, block in enumerate(self.blocks):
                 x, rgb = block.forward_(x, rgb, t[3 * i], t[3 * i + 1], t[3 * i + 2], inoise=input_noise)
             return rgb

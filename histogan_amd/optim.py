@@ -18,6 +18,14 @@ def _st(t):
     return raw_stream(t.device)
 
 
+def conv_first(params):
+    """`params` with the convolution weights (4-d tensors) first, order otherwise kept: the flat buffer then starts with one
+    contiguous region that holds every convolution weight (FlatParams.n_conv elements) -- the region whose gradients are final
+    when the last convolution's backward has been enqueued, long before the mapping networks' (DiffGrad.step_early)."""
+    params = list(params)
+    return [p for p in params if p.dim() == 4] + [p for p in params if p.dim() != 4]
+
+
 class FlatParams:
     """Re-home `params` (already on their final device) into one flat buffer; optionally with grads."""
 
@@ -30,6 +38,11 @@ class FlatParams:
                 self.params.append(p)
         if not self.params:
             raise ValueError('no parameters')
+        self.n_conv = 0       # elements of the leading run of 4-d parameters
+        for p in self.params:
+            if p.dim() != 4:
+                break
+            self.n_conv += p.numel()
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
         self.data = torch.empty(self.numel, dtype=torch.float32, device=dev)
@@ -155,11 +168,56 @@ class DiffGrad:
         reducer.finish()
         weights_changed(f.data)
 
+    def step_early(self, stream):
+        """The update of the flat buffer's leading convolution-weight region NOW, on `stream` -- legal as soon as every one of
+        those weights has its final gradient in its flat slot (all written directly: conv._direct_wgrad, the demodulation
+        term, gfused's to-RGB slot write), i.e. when the generator's fused backward node returns, while the mapping
+        networks' backward (a latency-bound chain of ~70 small launches) is still to run.  `step()` then updates the rest.
+        Returns False (nothing done) when a slot of the region was not written directly."""
+        f = self.flat
+        hi = f.n_conv
+        if hi <= 0 or self.graph_mode or not f.data.is_cuda or getattr(self, '_early', None) is not None or not f.direct_ok:
+            return False
+        base, off = f.grad.data_ptr(), 0
+        for p in f.params:
+            if off >= hi:
+                break
+            if base + 4 * off not in f.direct_written or p.grad is not None:
+                return False
+            off += p.numel()
+        from .conv import side_stream
+        dev = f.data.device
+        stream.wait_stream(side_stream(dev))                       # the weight gradients and demodulation terms
+        stream.wait_event(torch.cuda.current_stream(dev).record_event())   # slots written on the calling stream (to-RGB)
+        lr = self.param_groups[0]['lr']
+        with torch.cuda.stream(stream), on_device(dev):
+            check(lib.hg_diffgrad_step(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                       self.exp_avg_sq.data_ptr(), self.previous_grad.data_ptr(), hi, float(lr),
+                                       float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count + 1,
+                                       _st(f.data)), 'hg_diffgrad_step')
+        self._early = (hi, stream)
+        weights_changed(f.data)
+        return True
+
     def step(self):
         f = self.flat
         f.gather()
         if not f.data.is_cuda:
             raise RuntimeError('DiffGrad: parameters are not on a GPU; no CPU implementation')
+        early = self.__dict__.pop('_early', None)
+        if early is not None:         # the convolution-weight region was updated by step_early(): the rest now, same step number
+            lo, stream = early
+            self.step_count += 1
+            lr = self.param_groups[0]['lr']
+            with on_device(f.data.device):
+                if f.numel > lo:
+                    o = 4 * lo
+                    check(lib.hg_diffgrad_step(f.data.data_ptr() + o, f.grad.data_ptr() + o, self.exp_avg.data_ptr() + o,
+                                               self.exp_avg_sq.data_ptr() + o, self.previous_grad.data_ptr() + o, f.numel - lo,
+                                               float(lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                               self.step_count, _st(f.data)), 'hg_diffgrad_step')
+            torch.cuda.current_stream(f.data.device).wait_stream(stream)
+            return                    # (weights_changed() ran with the early part: the packed operands may already be rebuilt)
         if self.graph_mode:           # being captured: step size from device memory, counter advanced by prepare_replay()
             with on_device(f.data.device):
                 check(lib.hg_diffgrad_step_dev(f.data.data_ptr(), f.grad.data_ptr(), self.exp_avg.data_ptr(),

@@ -46,14 +46,15 @@ from .augment import AugWrapper
 from .conv import drain_pack_streams, enable_pack_cache, input_grads_only, prepack_async, weights_changed
 from .hist import hellinger_loss
 from .nets import Discriminator, Generator, HistVectorizer, StyleVectorizer
-from .optim import DiffGrad, FlatParams, ema_update
+from .optim import DiffGrad, FlatParams, conv_first, ema_update
 
 EPS = 1e-8
 EXTS = ['jpg', 'png']
 G_OVERLAP_DDP = os.environ.get('HG_G_OVERLAP_DDP', 'auto')   # the same under data parallelism: auto | 1 | 0 (see _device_step)
 G_OVERLAP = os.environ.get('HG_G_OVERLAP', '1') != '0'   # G-phase generator forward on a second stream beside the D phase
 G_STREAM_PRIO = int(os.environ.get('HG_G_STREAM_PRIO', '0'))   # HIP priority of that stream (0 normal, -1 high)
-H_SIDE = os.environ.get('HG_H_SIDE', '1') != '0'               # D phase: histogram vectorizer on a second stream beside S
+H_SIDE = os.environ.get('HG_H_SIDE', '1') != '0'               # histogram vectorizer on a second stream beside S
+H_SIDE_GRAD = os.environ.get('HG_H_SIDE_GRAD', '1') != '0'     # ... in the grad-enabled G-phase forward too (its backward then runs there as well)
 BATCH_S = os.environ.get('HG_BATCH_S', '1') != '0'             # both latent batches of a mixed draw through S at once
 D_STEP_EARLY = os.environ.get('HG_D_STEP_EARLY', '1') != '0'   # D's optimizer step before main waits for that stream
 # Plain steps replayed from a captured hipGraph (single process): HG_GRAPH = auto (default) | 1 | 0 | 2.
@@ -67,6 +68,10 @@ D_STEP_EARLY = os.environ.get('HG_D_STEP_EARLY', '1') != '0'   # D's optimizer s
 GRAPH_MODE = os.environ.get('HG_GRAPH', 'auto')
 GRAPH_AUTO_RATIO = float(os.environ.get('HG_GRAPH_AUTO_RATIO', '0.9'))
 GRAPH_GP = os.environ.get('HG_GRAPH_GP', '1') != '0'      # gradient-penalty steps replay from their own graph too
+# G's convolution weights updated + re-packed under the tail of its backward (DiffGrad.step_early).  Measured at C3
+# (profiles/r06_ab_early_gopt.json): 865.7 images/s with it, 867.7 without -- the HBM-bound update beside the latency-bound
+# mapping-network backward slows that chain by what it saves at the step boundary; off by default.
+EARLY_GOPT = os.environ.get('HG_EARLY_GOPT', '0') != '0'
 LAZY_STATS = os.environ.get('HG_LAZY_STATS', '1') != '0'  # statistics of step n read while step n+1 is queued (0: blocking read-back every step)
 
 
@@ -237,10 +242,11 @@ class HistoGAN(nn.Module):
             device = torch.device('cuda', torch.cuda.current_device())
         self.to(device)
         # flat storage (after the move): generator side in the reference's optimizer order G, S, H (:668-670)
-        self._flat_g = FlatParams(list(self.G.parameters()) + list(self.S.parameters()) + list(self.H.parameters()))
+        # (convolution weights first: DiffGrad.step_early updates that region while the mapping networks' backward still runs)
+        self._flat_g = FlatParams(conv_first(list(self.G.parameters()) + list(self.S.parameters()) + list(self.H.parameters())))
         self._flat_d = FlatParams(self.D.parameters())
-        self._flat_ema = FlatParams(list(self.GE.parameters()) + list(self.SE.parameters()) +
-                                    list(self.HE.parameters()), with_grad=False)
+        self._flat_ema = FlatParams(conv_first(list(self.GE.parameters()) + list(self.SE.parameters()) +
+                                               list(self.HE.parameters())), with_grad=False)
         self.G_opt = DiffGrad(self._flat_g, lr=self.lr, betas=(0.5, 0.9))
         self.D_opt = DiffGrad(self._flat_d, lr=self.lr, betas=(0.5, 0.9))
         # replicas start identical under data parallelism
@@ -419,10 +425,11 @@ class Trainer():
 
     def _w_and_hw(self, style, hist_batch):
         GAN = self.GAN
-        if (H_SIDE and hist_batch.is_cuda and not torch.is_grad_enabled()
+        if (H_SIDE and hist_batch.is_cuda and (H_SIDE_GRAD or not torch.is_grad_enabled())
                 and not torch.cuda.is_current_stream_capturing()):
-            # no autograd (the D phase): the histogram vectorizer beside the mapping network instead of behind it -- two
-            # independent chains of 8 small serial GEMMs at the head of the generator forward
+            # the histogram vectorizer beside the mapping network instead of behind it -- two independent chains of 8 small
+            # serial GEMMs at the head of the generator forward; with autograd recording, the engine runs each chain's
+            # backward on the stream of its forward: the two chains are side by side at the tail of the backward as well
             from .nets import aux_stream
             main, aux = torch.cuda.current_stream(hist_batch.device), aux_stream(hist_batch.device)
             aux.wait_event(main.record_event())
@@ -715,7 +722,8 @@ class Trainer():
         else:
             GAN._reduce_g()
             GAN.G_opt.step()
-        prepack_async(GAN._flat_g.data)        # next step's generator operands, under the head of its forward
+        if not self.__dict__.pop('_early_packed', False):
+            prepack_async(GAN._flat_g.data)    # next step's generator operands, under the head of its forward
         mark('g_optimizer')
 
         return torch.stack([total_disc_loss, total_gen_loss, total_hist_loss, gp_val.reshape(()),
@@ -752,6 +760,7 @@ class Trainer():
                 d_updated = True
             self._mark('g_forward_joined_d_updated')
             fake_output, _ = Disc(aug(generated_images))
+            self._mark('g_phase_d_forward')
             generated_histograms = self.histBlock(generated_images, pre_relu=True)   # == histBlock(F.relu(.)), reference :955
             histogram_loss = hellinger_loss(hist_batch, generated_histograms, alpha)
             loss = fake_output.mean()
@@ -770,7 +779,16 @@ class Trainer():
                         gen_loss = gen_loss + pl_loss
             gen_loss = gen_loss / acc
             self._mark('g_phase_d_forward_hist_loss')
-            gen_loss.backward()
+            early_opt = (EARLY_GOPT and acc == 1 and not apply_path_penalty and not ddp.is_dist()
+                         and not torch.cuda.is_current_stream_capturing())
+            if early_opt:
+                from . import gfused
+                gfused.AFTER_BLOCKS = self._early_g_update
+            try:
+                gen_loss.backward()
+            finally:
+                if early_opt:
+                    gfused.AFTER_BLOCKS = None
             self._mark('g_backward')
             total_gen_loss = total_gen_loss + loss.detach() / acc
             total_hist_loss = total_hist_loss + histogram_loss.detach() / acc
@@ -850,6 +868,18 @@ class Trainer():
             self.evaluate(floor(self.steps / 1000))
         self.steps += 1
         self.av = None
+
+    def _early_g_update(self):
+        """Called by the generator's fused backward node when its last convolution weight gradient is enqueued: DiffGrad on the
+        convolution-weight region of G's flat buffer and the re-pack of its operands run on a stream of their own beside the
+        rest of the backward (mapping networks, style projections); `G_opt.step()` finishes the other parameters."""
+        GAN = self.GAN
+        st = self.__dict__.get('_opt_stream')
+        if st is None:
+            st = self._opt_stream = torch.cuda.Stream(device=self.device)
+        if GAN.G_opt.step_early(st):
+            with torch.cuda.stream(st):
+                self._early_packed = bool(prepack_async(GAN._flat_g.data))
 
     def _mark(self, name):
         """Phase marker of the step on the CURRENT stream (tools/phase_probe.py sets `phase_events = []`; None: no-op)."""

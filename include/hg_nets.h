@@ -48,6 +48,25 @@ size_t hg_torgb_bwd_workspace_bytes(int32_t B, int32_t O, int32_t C, int32_t HW)
 int hg_torgb_bwd(const float *g, const float *x, const float *s, const float *w, float *gx, float *gs, float *gw, int32_t B,
                  int32_t O, int32_t C, int32_t HW, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- everything between two convolutions of the generator's backward as ONE pass (hg_gstage.hip) ----------------------
+ * A stage output  out = lrelu_0.2(d conv + wn nz + bn)  (GeneratorBlock.forward, histoGAN/histoGAN.py:461-479) with its
+ * consumers: A = the next modulated convolution (same resolution, up = 0: Conv2DMod :420-424; or behind the bilinear x2 of
+ * the next block, up = 1: :447-448, 463-464) and R = the block's to-RGB convolution (RGBBlock :380-390).  Replaces the chain
+ * hg_modulate_bwd + hg_torgb_bwd + add + hg_demod_noise_lrelu_bwd (conv = NULL form) with one read of each operand:
+ *   t = up ? up2^T(ga) : ga;  tr = sum_k w_rgb[k,c] g_rgb[b,k,p];  G = t (sa + 1) + tr (s_rgb + 1);  m = G (out > 0 ? 1 : 0.2)
+ *   gconv = m d[b,c]                                  (B,C,H,H): the upstream gradient of the stage's convolution
+ *   gs_a[b,c]  = sum_p out t                          (NULL iff sa is NULL)          style gradient of A (modulation part)
+ *   gs_rgb[b,c] = sum_p out tr,  gw_rgb[k,c] = sum_{b,p} g_rgb[b,k,p] (s_rgb[b,c] + 1) out[b,c,p]
+ *   gd[b,c] = sum_p m conv  (conv recovered from out; NULL iff d is NULL),  gwn[c] = sum_{b,p} m nz,  gbn[c] = sum_{b,p} m
+ * out (B,C,H,H); ga (B,C,H,H) or (B,C,2H,2H) or NULL; g_rgb (B,Cr,H,H) or NULL (not both NULL), Cr <= 4; nzt (B,S,S) as in
+ * hg_demod_noise_lrelu_fwd.  H % 4 == 0, S % 4 == 0 (HG_EUNSUPPORTED otherwise).  Deterministic (partial sums in the
+ * workspace, combined in fixed order). */
+size_t hg_gstage_bwd_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t up);
+int hg_gstage_bwd(const float *out, const float *ga, const float *sa, int32_t up, const float *g_rgb, const float *w_rgb,
+                  const float *s_rgb, int32_t Cr, const float *d, const float *nzt, const float *wn, const float *bn, int32_t S,
+                  float *gconv, float *gs_a, float *gs_rgb, float *gw_rgb, float *gd, float *gwn, float *gbn, int32_t B,
+                  int32_t C, int32_t H, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Scratch (partial sums, combined in fixed order: deterministic) for hg_modulate_bwd / hg_demod_noise_lrelu_bwd /
  * hg_channel_sum on a (B, C, H, W) tensor. */
 size_t hg_nets_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W);

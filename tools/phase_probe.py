@@ -30,6 +30,16 @@ for _ in range(3):
     tr.steps = a.index
     tr.train()
 torch.cuda.synchronize()
+import histogan_amd.nets as HN  # noqa: E402
+
+
+def hook(name, any_stream=False):   # marks inside the networks: on the step's main stream (the side-stream forward overlaps
+    # other phases), or -- backward nodes, which the engine runs one after the other -- on whatever stream they run
+    if tr.__dict__.get('phase_events') is not None and (any_stream or torch.cuda.current_stream() == torch.cuda.default_stream()):
+        tr._mark(name)
+
+
+HN.PHASE_HOOK = hook
 rows = []
 for _ in range(a.steps):
     tr.steps = a.index
