@@ -23,6 +23,7 @@ from ._lib import check, lib, on_device, raw_stream
 
 GFUSED = os.environ.get('HG_GFUSED', '1') != '0'
 PER_BLOCK = 10        # tensors per block in the Function's argument list (see generator_train)
+DEMOD_AUX = os.environ.get('HG_DEMOD_AUX', '0') != '0'
 AFTER_BLOCKS = None    # trainer: called when the node's backward has enqueued the last convolution weight gradient
 STAGE_OBSERVER = None  # tests: called with every stage output (two per block, forward order) -- the LeakyReLU branches taken
 
@@ -188,7 +189,27 @@ class _GeneratorTrain(torch.autograd.Function):
         g_rgb = _f32c(g)
         ga = None          # d loss / d (modulated, up-sampled input of the NEXT block's first convolution)
         sa = None
-        gy_next = None     # demodulation part of the style gradient of the next block's first convolution
+        # The demodulation coefficients' adjoints (a small GEMM-like kernel pair + the weight term per convolution) only feed
+        # the style gradients returned at the end.  HG_DEMOD_AUX=1 runs them on the auxiliary stream, off the dgrad -> stage ->
+        # dgrad chain: measured 854.6 vs 867.7 images/s inline (they already hide under the weight-gradient kernels) -- off.
+        dev = g_rgb.device
+        main, aux = torch.cuda.current_stream(dev), _N.aux_stream(dev)
+        pend = []          # (index into grads, modulation part, demodulation part)
+        wterm = {}
+
+        def demod_async(idx, gd, d, s1p, wsq, wp):
+            if not DEMOD_AUX or torch.cuda.is_current_stream_capturing():
+                gy, wterm[idx] = _demod_bwd(gd, d, s1p, wsq, wp)
+                return gy
+            aux.wait_event(main.record_event())
+            with torch.cuda.stream(aux):
+                gy, gwd = _demod_bwd(gd, d, s1p, wsq, wp)
+            gd.record_stream(aux)
+            gy.record_stream(main)
+            if gwd is not None:
+                gwd.record_stream(main)
+            wterm[idx] = gwd
+            return gy
         for i in range(L - 1, -1, -1):
             xm1, out1, xm2, out2, s1, s2, srgb, d1, d2, wn1, bn1, wn2, bn2, s1p, s2p, wsq1, wsq2 = blk(i)
             w1p, w2p, wrgbp = ctx.weights[i]
@@ -204,7 +225,7 @@ class _GeneratorTrain(torch.autograd.Function):
                                                                        srgb, d2, nzt, wn2, bn2,
                                                                        None if slot is None else slot[0].view(Cr, -1))
             if ga is not None:
-                grads[base + PER_BLOCK + 0] = gs_a + gy_next     # style of the next block's conv1: modulation + demodulation parts
+                pend.append((base + PER_BLOCK + 0, gs_a, gy_next))   # style of the next block's conv1: modulation + demodulation parts
             grads[base + 2] = gs_rgb
             if slot is None:
                 grads[base + 5] = gw_rgb.reshape(wrgbp.shape)
@@ -212,27 +233,32 @@ class _GeneratorTrain(torch.autograd.Function):
                 slot[1].direct_written.add(slot[0].data_ptr())
             grads[base + 8], grads[base + 9] = gwn2.reshape(-1, 1), gbn2
             g_xm2 = C.conv_dgrad_packed(gconv2, C.pack_weights(w2, C.PACK_DGRAD), w2.shape[1], xm2.shape[2], xm2.shape[3], 3)
-            gw2 = _wgrad(w2p, xm2, gconv2)
-            gy2, gw2d = _demod_bwd(gd2, d2, s2p, wsq2, w2p)
-            grads[base + 4] = _add(gw2, gw2d)
+            grads[base + 4] = _wgrad(w2p, xm2, gconv2)
+            gy2 = demod_async(base + 4, gd2, d2, s2p, wsq2, w2p)
             if i > 0:                                            # rgb_i = to_rgb(out2) + up2(rgb_{i-1})
                 g_rgb_prev, _ = _modulate_bwd(g_rgb, torch.empty((g_rgb.shape[0], Cr, g_rgb.shape[2] // 2, g_rgb.shape[3] // 2),
                                                                  dtype=torch.float32, device=g_rgb.device), None, True)
             # ---- at out1: conv2 (same resolution) -> conv1's upstream gradient
             gconv1, gs2, _, _, gd1, gwn1, gbn1 = gstage_bwd(out1, g_xm2, s2, False, None, None, None, d1, nzt, wn1, bn1)
-            grads[base + 1] = gs2 + gy2
+            pend.append((base + 1, gs2, gy2))
             grads[base + 6], grads[base + 7] = gwn1.reshape(-1, 1), gbn1
             ga = C.conv_dgrad_packed(gconv1, C.pack_weights(w1, C.PACK_DGRAD), w1.shape[1], xm1.shape[2], xm1.shape[3], 3)
-            gw1 = _wgrad(w1p, xm1, gconv1)
-            gy_next, gw1d = _demod_bwd(gd1, d1, s1p, wsq1, w1p)
-            grads[base + 3] = _add(gw1, gw1d)
+            grads[base + 3] = _wgrad(w1p, xm1, gconv1)
+            gy_next = demod_async(base + 3, gd1, d1, s1p, wsq1, w1p)
             sa = s1
             if i > 0:
                 g_rgb = g_rgb_prev
         # block 0's first convolution reads the learned constant directly (no upsample)
         gx0e, gs1_0 = _modulate_bwd(ga, x0e, sa, False)
-        grads[0] = gs1_0 + gy_next
+        pend.append((0, gs1_0, gy_next))
         g_x0 = gx0e.sum(0)
+        if DEMOD_AUX and not torch.cuda.is_current_stream_capturing():
+            main.wait_stream(aux)
+        torch._foreach_add_([a for _, a, _ in pend], [b for _, _, b in pend])
+        for idx, a, _ in pend:
+            grads[idx] = a
+        for idx, gwd in wterm.items():
+            grads[idx] = _add(grads[idx], gwd)
         if _N.PHASE_HOOK is not None:
             _N.PHASE_HOOK('gb_generator_blocks_done', True)
         if AFTER_BLOCKS is not None:
@@ -240,9 +266,59 @@ class _GeneratorTrain(torch.autograd.Function):
         return (g_x0, None, *grads)
 
 
-def supported(gen, styles_t, nzt):
+def generator_infer(gen, styles_t, nzt):
+    """The same launch sequence without autograd (the D phase's generator forward, evaluate()): modulation inside the
+    convolution kernel where there is no upsample in front of it, and the 14 demodulation coefficients -- six small dependent
+    launches each, ~0.4 ms as links of the convolution chain -- computed AHEAD on the auxiliary stream (they depend on the
+    styles and the weights only); the chain waits for its block's event."""
+    dev = nzt.device
+    main, aux = torch.cuda.current_stream(dev), nets_aux(dev)
+    L = len(gen.blocks)
+    B = styles_t[0].shape[0]
+    S = nzt.shape[-1]
+    aux.wait_event(main.record_event())
+    ahead = []
+    with torch.cuda.stream(aux):
+        for i, b in enumerate(gen.blocks):
+            w1, w2 = _f32c(b.conv1.weight), _f32c(b.conv2.weight)
+            d1, s1p, _ = _demod(_f32c(styles_t[3 * i]), w1)
+            d2, s2p, _ = _demod(_f32c(styles_t[3 * i + 1]), w2)
+            ahead.append((d1, s1p, d2, s2p, aux.record_event()))
+    for t in styles_t:
+        t.record_stream(aux)
+    x = _f32c(gen.initial_block).expand(B, -1, -1, -1).contiguous()
+    prev = rgb = None
+    for i, b in enumerate(gen.blocks):
+        d1, s1p, d2, s2p, ev = ahead[i]
+        main.wait_event(ev)
+        for t in (d1, s1p, d2, s2p):
+            t.record_stream(main)
+        w1, w2, wrgb = _f32c(b.conv1.weight), _f32c(b.conv2.weight), _f32c(b.to_rgb.conv.weight)
+        wn1, bn1 = _f32c(b.to_noise1.weight).reshape(-1), _f32c(b.to_noise1.bias)
+        wn2, bn2 = _f32c(b.to_noise2.weight).reshape(-1), _f32c(b.to_noise2.bias)
+        N = w1.shape[0]
+        if i:
+            x, isc = _modulate(x, _f32c(styles_t[3 * i]), True), None
+        else:
+            isc = s1p
+        x = C.modconv_fwd_packed(x, C.pack_weights(w1, C.PACK_FWD), N, 3, isc, d1, bn1, wn1, nzt, S, 0.2)
+        x = C.modconv_fwd_packed(x, C.pack_weights(w2, C.PACK_FWD), N, 3, s2p, d2, bn2, wn2, nzt, S, 0.2)
+        rgb = _torgb(x, _f32c(styles_t[3 * i + 2]), wrgb.reshape(wrgb.shape[0], -1), prev)
+        if i != L - 1:
+            prev = _modulate(rgb, None, True)
+    return rgb
+
+
+def nets_aux(dev):
+    from .nets import aux_stream
+    return aux_stream(dev)
+
+
+def supported(gen, styles_t, nzt, train=True):
     """Shapes / options the fused node serves (everything HistoGAN trains with); anything else takes the per-block path."""
-    if not (GFUSED and torch.is_grad_enabled() and nzt.is_cuda and nzt.dtype == torch.float32):
+    if not (GFUSED and torch.is_grad_enabled() == train and nzt.is_cuda and nzt.dtype == torch.float32):
+        return False
+    if not train and torch.cuda.is_current_stream_capturing():
         return False
     S = nzt.shape[-1]
     if S % 4 or gen.initial_block.shape[-1] % 4 or gen.initial_block.shape[-1] != gen.initial_block.shape[-2]:

@@ -238,6 +238,8 @@ class Generator(nn.Module):
                 if gfused.supported(self, t, nzt):
                     # training: the whole network as ONE autograd node with a hand-written backward (gfused.py)
                     return gfused.generator_train(self, t, nzt)
+                if gfused.supported(self, t, nzt, train=False):
+                    return gfused.generator_infer(self, t, nzt)
             for i, block in enumerate(self.blocks):
                 x, rgb = block.forward_(x, rgb, t[3 * i], t[3 * i + 1], t[3 * i + 2], inoise=input_noise)
             return rgb

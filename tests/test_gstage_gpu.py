@@ -106,6 +106,17 @@ def test_fused_generator_node_equals_per_block_autograd(size, cap, B, gpu_device
             gfused.GFUSED = True
         res[mode] = (rgb.detach(), grads)
     assert relmax(res[True][0].cpu().numpy(), res[False][0].cpu().numpy()) <= 1e-6
+    # the no-autograd twin (gfused.generator_infer: in-kernel modulation, demodulation coefficients ahead on a second stream)
+    with torch.no_grad():
+        inf = G(styles, hists, noise)
+        gfused.GFUSED = False
+        try:
+            inf_ref = G(styles, hists, noise)
+        finally:
+            gfused.GFUSED = True
+    torch.cuda.synchronize()
+    assert relmax(inf.cpu().numpy(), inf_ref.cpu().numpy()) <= 1e-6
+    assert relmax(inf.cpu().numpy(), res[False][0].cpu().numpy()) <= 2e-6
     names = ['styles', 'hists'] + [n for n, _ in G.named_parameters()]
     for n, a, b_ in zip(names, res[True][1], res[False][1]):
         assert relmax(a.cpu().numpy(), b_.cpu().numpy()) <= 2e-5, n
