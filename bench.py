@@ -471,6 +471,25 @@ def cpu_baseline(args):
                        f'{torch.get_num_threads()} threads, {dt:.2f} s; 1 warm-up + median of {args.cpu_reps}')
 
 
+def cpu_baseline_hist_c1(args):
+    """configs[0] of BASELINE.json (C1): RGBuvHistBlock forward + Hellinger loss on 4 x 3 x 128 x 128 random RGB, the reference
+    notebook's CPU path (Histogram_loss.ipynb:394-417; h = 64, insz = 150: no resize at 128), on the oracle (the restated
+    PyTorch CPU chain), all host threads.  Forward + loss is the notebook's case; forward + loss + backward beside it."""
+    from oracle import rgbuv_hist as O
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(4, 3, 128, 128, generator=g)
+    tgt = O.rgbuv_hist(torch.rand(4, 3, 128, 128, generator=torch.Generator().manual_seed(1)), h=64, insz=150)
+
+    def fwd_loss():
+        with torch.no_grad():
+            return O.hellinger_loss(tgt, O.rgbuv_hist(x, h=64, insz=150))
+    dt_f = _median_time(fwd_loss, reps=5)
+    dt_fb = _median_time(lambda: O.rgbuv_hist_fwd_bwd(x, target=tgt, alpha=1.0, h=64, insz=150), reps=5)
+    return dict(value=4 / dt_f, unit='images/s', cores=torch.get_num_threads(), kind='port', cpu=cpu_model(),
+                ms_fwd_loss=dt_f * 1e3, ms_fwd_loss_bwd=dt_fb * 1e3, images_per_s_fwd_loss_bwd=4 / dt_fb,
+                sample='the whole C1 case: 4x3x128x128, h=64, inverse-quadratic; 1 warm-up + median of 5')
+
+
 def ddp_probe(dist, dev, rank, world, tr):
     """Self-check of the data-parallel set-up for the driver's SCALE record: every rank reports the world size / backend
     it sees and its device, and the gradient all-reduces of one step are timed stand-alone (outside the timed region):
@@ -507,28 +526,6 @@ def ddp_probe(dist, dev, rank, world, tr):
     info['allreduce'] = res
     info['allreduce_ms_per_step'] = sum(v['ms'] for v in res.values())
     return info
-
-
-def alt_precision_line(args):
-    """The same train workload with the 3x3 stride-1 convolutions on the bf16 matrix cores through exact three-way splits
-    (HG_CONV_PRECISION=b6: six bf16 products per fp32 product, fp32 accumulation) -- a labelled SECONDARY
-    number: the headline `value`, `dtype` and `roofline` stay on the fp32-MFMA kernels.  It is reported because the whole C3
-    parity suite holds its 1e-5 / 1e-4 gates in this mode (profiles/r04_c3_parity_b6.json).  Run in a child process (the
-    precision switch is read at import)."""
-    import subprocess
-    env = dict(os.environ, HG_CONV_PRECISION='b6')
-    cmd = [sys.executable, os.path.abspath(__file__), '--workload', 'train', '--steps', str(min(args.steps, 32)), '--warmup', str(args.warmup),
-           '--batch', str(args.batch), '--size', str(args.size), '--capacity', str(args.capacity), '--bins', str(args.bins),
-           '--no-roofline', '--no-cpu-baseline', '--no-reference-eager', '--no-alt-precision']
-    try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-        line = [l for l in r.stdout.splitlines() if l.strip().startswith('{')][-1]
-        d = json.loads(line)
-        return {'mode': 'bf16x6 split of every fp32 operand, fp32 accumulate (3x3 stride-1 output / data-gradient convolutions; '
-                        'weight gradients and everything else fp32 MFMA)', 'images_per_s': d['value'], 'ms_per_step': d['ms_per_step'],
-                'steps': d['steps'], 'parity_record': 'profiles/r04_c3_parity_b6.json', 'env': 'HG_CONV_PRECISION=b6'}
-    except Exception as e:
-        return {'mode': 'bf16x6', 'images_per_s': None, 'error': f'{type(e).__name__}: {str(e)[:200]}'}
 
 
 def claim_stdout():
@@ -628,7 +625,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-reference-eager', action='store_true')
     ap.add_argument('--no-roofline', action='store_true', help='skip the stand-alone kernel timings (tests only)')
-    ap.add_argument('--no-alt-precision', action='store_true', help='skip the labelled bf16x6 secondary line')
+    ap.add_argument('--no-alt-precision', action='store_true', help='(accepted and ignored: the bf16x6 secondary line was removed in round 6)')
     args = ap.parse_args()
 
     if args.workload == 'c5':
@@ -862,12 +859,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if args.workload != 'rehistogan':      # the CPU baseline is quoted for the headline workloads only
                 out['cpu_baseline'] = cpu_baseline_train(args) if args.workload == 'train' else cpu_baseline(args)
+                out['cpu_baseline_hist_c1'] = cpu_baseline_hist_c1(args)
             if args.workload == 'train' and not args.no_reference_eager:
                 out['reference_eager_rocm'] = reference_eager_rocm(args, dev)
-        if world == 1 and args.workload == 'train' and not args.no_alt_precision and not getattr(args, 'c5', False) \
-                and os.environ.get('HG_CONV_PRECISION', 'f32') == 'f32':
-            torch.cuda.empty_cache()
-            out['alt_precision'] = alt_precision_line(args)
         print(json.dumps(out), file=json_out, flush=True)
     if dist:
         dist.destroy_process_group()

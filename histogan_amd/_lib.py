@@ -134,14 +134,6 @@ def _load():
     lib.hg_conv2d_plan.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(ctypes.c_int32)]
     lib.hg_conv2d_dgrad.restype = ctypes.c_int
     lib.hg_conv2d_dgrad.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, sz, vp]
-    lib.hg_conv_b6_packed_bytes.restype = sz
-    lib.hg_conv_b6_packed_bytes.argtypes = [i32, i32, i32]
-    lib.hg_conv_b6_pack_weights.restype = ctypes.c_int
-    lib.hg_conv_b6_pack_weights.argtypes = [vp, vp, i32, i32, i32, vp]
-    lib.hg_conv2d_b6.restype = ctypes.c_int
-    lib.hg_conv2d_b6.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
-    lib.hg_conv2d_b9.restype = ctypes.c_int
-    lib.hg_conv2d_b9.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.hg_conv2d_wgrad_workspace_bytes.restype = sz
     lib.hg_conv2d_wgrad_workspace_bytes.argtypes = [i32, i32, i32, i32, i32, i32, i32]
     lib.hg_conv2d_wgrad.restype = ctypes.c_int
@@ -209,7 +201,7 @@ EXPORTS = ('hg_version', 'hg_error_string', 'hg_rgbuv_hist_workspace_bytes', 'hg
            'hg_diffgrad_step', 'hg_diffgrad_step_size', 'hg_diffgrad_step_dev', 'hg_ema_update', 'hg_nets_workspace_bytes', 'hg_channel_sum', 'hg_lrelu_bwd_channel_sum', 'hg_demod_weight_term', 'hg_demod_style_grad', 'hg_demod_style_grad_workspace_bytes',
            'hg_conv_packed_elems', 'hg_conv_pack_weights', 'hg_conv_pack_weights_both', 'hg_conv_pack_blocks', 'hg_conv_pack_weights_multi', 'hg_conv2d_fwd', 'hg_conv2d_fwd_add', 'hg_modconv2d_fwd', 'hg_conv2d_workspace_bytes', 'hg_conv2d_plan', 'hg_conv2d_dgrad',
            'hg_conv2d_wgrad_workspace_bytes',
-           'hg_conv2d_wgrad', 'hg_conv_b6_packed_bytes', 'hg_conv_b6_pack_weights', 'hg_conv2d_b6', 'hg_conv2d_b9',
+           'hg_conv2d_wgrad',
            'hg_instnorm_workspace_bytes', 'hg_instnorm_lrelu_fwd', 'hg_instnorm_lrelu_bwd', 'hg_stencil3',
            'hg_depthwise_valid', 'hg_augment_spatial', 'hg_augment_workspace_bytes', 'hg_sample_mean',
            'hg_augment_color', 'hg_grouped_linear_fwd', 'hg_grouped_linear_bwd_input_workspace_bytes',

@@ -21,18 +21,6 @@ from ._lib import check, lib, on_device, raw_stream
 PACK_FWD, PACK_DGRAD = 0, 1
 _skip_wgrad = False
 
-# Precision plan of the 3x3 stride-1 output / data-gradient convolutions:
-#   'f32'   v_mfma_f32_32x32x2_f32 (k_conv)            -- default
-#   'b6'    three-way bf16 split, six bf16 MFMAs per fp32 product sum (k_conv_b6): fp32-level accuracy at 2.7x the
-#           fp32-MFMA ceiling.  Used for layers with >= 16 input channels and >= B6_MIN_PIX output pixels.
-PRECISION = os.environ.get('HG_CONV_PRECISION', 'f32')
-B6_MIN_PIX = 4096
-
-
-def _use_b6(K, N, H, W, B, k, stride):
-    return PRECISION in ('b6', 'b9') and k == 3 and stride == 1 and K >= 16 and B * H * W >= B6_MIN_PIX
-
-
 # Winograd F(2x2, 3x3) for the 3x3 stride-1 output / data-gradient launches (include/hg_wino.h): the packed operand of a
 # weight carries its transformed twin as the attribute `.wino` (registered weights: written by the batched pack; others:
 # packed on first use from `.wino_src`); a launch takes it when hg_wino_supported says the shape is served and faster.
@@ -455,28 +443,6 @@ def _await_pack(owner, device, key=None):
                 seen.add(cur.cuda_stream)
 
 
-def pack_b6(w, mode):
-    """(Co,Ci,3,3) -> the split-bf16 operand of hg_conv2d_b6 (cached like pack_weights for registered weights)."""
-    def make(t):
-        Co, Ci = t.shape[0], t.shape[1]
-        nbytes = lib.hg_conv_b6_packed_bytes(Co, Ci, mode)
-        with on_device(t.device):
-            wt = torch.empty(nbytes, dtype=torch.uint8, device=t.device)
-            check(lib.hg_conv_b6_pack_weights(t.data_ptr(), wt.data_ptr(), Co, Ci, mode, _st(t)), 'hg_conv_b6_pack_weights')
-        return wt
-    return cached(w, ('b6', mode), make)
-
-
-def conv_b6(x, wt, N, bias=None, nprod=None):
-    """nprod: 6 (bf16x6) or 9 (bf16x9: exact products); default from HG_CONV_PRECISION."""
-    B, K, H, W = x.shape
-    fn = lib.hg_conv2d_b9 if (nprod or (9 if PRECISION == 'b9' else 6)) == 9 else lib.hg_conv2d_b6
-    with on_device(x.device):
-        out = torch.empty((B, N, H, W), dtype=torch.float32, device=x.device)
-        check(fn(x.data_ptr(), wt.data_ptr(), out.data_ptr(), _ptr(bias), B, K, N, H, W, _st(x)), 'hg_conv2d_b6/b9')
-    return out
-
-
 def _pack_both(w):
     Co, Ci, k, _ = w.shape
     with on_device(w.device):
@@ -751,8 +717,6 @@ class _Conv(torch.autograd.Function):
         ctx.stride, ctx.has_bias = stride, bias is not None
         xc, wc = _f32c(x), _f32c(w)
         bc = None if bias is None else _f32c(bias)
-        if _use_b6(xc.shape[1], w.shape[0], xc.shape[2], xc.shape[3], xc.shape[0], w.shape[2], stride):
-            return conv_b6(xc, pack_b6(wc, PACK_FWD), w.shape[0], bc)
         return conv_fwd_packed(xc, pack_weights(wc, PACK_FWD), w.shape[0], w.shape[2], stride, bias=bc)
 
     @staticmethod
@@ -782,8 +746,6 @@ class _ConvDgrad(torch.autograd.Function):
         ctx.save_for_backward(g, w)
         ctx.stride = stride
         gc, wc = _f32c(g), _f32c(w)
-        if _use_b6(w.shape[0], w.shape[1], H, W, gc.shape[0], w.shape[2], stride):
-            return conv_b6(gc, pack_b6(wc, PACK_DGRAD), w.shape[1])
         return conv_dgrad_packed(gc, pack_weights(wc, PACK_DGRAD), w.shape[1], H, W, w.shape[2], stride)
 
     @staticmethod
@@ -930,7 +892,7 @@ def conv2d(x, w, bias=None, stride=1):
 
 def conv2d_add(x, w, bias, addend, stride=1):
     """F.conv2d(x, w, bias, stride, padding=k//2) + addend as one launch."""
-    if _batch_pieces(x, w, stride) != 1 or _use_b6(x.shape[1], w.shape[0], x.shape[2], x.shape[3], x.shape[0], w.shape[2], stride):
+    if _batch_pieces(x, w, stride) != 1:
         return conv2d(x, w, bias, stride) + addend
     return _ConvAdd.apply(x, w, bias, addend, stride)
 

@@ -114,21 +114,6 @@ int hg_conv2d_wgrad(const float *in, const float *gout, float *gw, const float *
                     int32_t B, int32_t K, int32_t N, int32_t Hi, int32_t Wi, int32_t ksize, int32_t stride,
                     void *workspace, size_t workspace_bytes, void *stream);
 
-/* ---- 3x3 stride-1 convolution on the bf16 matrix cores at fp32 accuracy ("bf16x6", hg_conv_b6.hip) ----------------
- * Each fp32 operand is split exactly into three bf16 numbers; six v_mfma_f32_32x32x16_bf16 products per 16 input
- * channels reproduce the fp32 product sum to fp32 rounding level (fp32 accumulation), at 6/16 of the fp32-MFMA time.
- * Packed operand: hg_conv_b6_packed_bytes bytes, written by hg_conv_b6_pack_weights (mode as above: FWD for the output,
- * DGRAD for the data gradient, where K / N swap roles as in hg_conv2d_dgrad).  out = conv(in, W) + bias. */
-size_t hg_conv_b6_packed_bytes(int32_t Co, int32_t Ci, int32_t mode);
-int hg_conv_b6_pack_weights(const float *w, void *wt, int32_t Co, int32_t Ci, int32_t mode, void *stream);
-int hg_conv2d_b6(const float *in, const void *wt, float *out, const float *bias, int32_t B, int32_t K, int32_t N,
-                 int32_t H, int32_t W, void *stream);
-/* The same with all nine bf16 partial products ("bf16x9"): every partial product is exact in fp32 and they sum to the
- * exact fp32 product, so only the accumulation order differs from the fp32 MFMA's fma chain; 9/16 of its matrix-pipe time.
- * Same packed operand as hg_conv2d_b6. */
-int hg_conv2d_b9(const float *in, const void *wt, float *out, const float *bias, int32_t B, int32_t K, int32_t N,
-                 int32_t H, int32_t W, void *stream);
-
 #ifdef __cplusplus
 }
 #endif
