@@ -150,6 +150,45 @@ class GradAllReduce:
         self.finish()
 
 
+class _GlobalStd(torch.autograd.Function):
+    """Unbiased std over dim 0 of the GLOBAL batch, this rank holding a shard of it.  Forward: one all-reduce of the moments
+    sum(x), sum(x^2) (fp64: the variance is a difference of the two) and the count.  Backward: the incoming gradient is
+    all-reduced (SUM) first -- every rank's loss depends on the one global statistic, so d(sum of the ranks' losses)/d std
+    is the sum of the ranks' gradients -- then d std / d x_i = (x_i - mean) / ((n - 1) std) for this rank's rows.  With the
+    rank-AVERAGED parameter gradients of the data-parallel step this reproduces the single-process gradient exactly."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xd = x.detach().double()
+        k = xd[0].numel()
+        m = torch.cat([xd.sum(dim=0).reshape(-1), (xd * xd).sum(dim=0).reshape(-1),
+                       torch.full((1,), float(x.shape[0]), dtype=torch.float64, device=x.device)])
+        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+        n = m[-1]
+        mean = (m[:k] / n).reshape((1,) + tuple(x.shape[1:]))
+        var = ((m[k:2 * k] - m[:k] * m[:k] / n) / (n - 1.0)).reshape(mean.shape)
+        std = torch.sqrt(torch.clamp(var, min=0.0))
+        ctx.save_for_backward(xd, mean, std, n)
+        return std.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        xd, mean, std, n = ctx.saved_tensors
+        G = g.detach().double().clone()
+        dist.all_reduce(G, op=dist.ReduceOp.SUM)
+        gx = G * (xd - mean) / ((n - 1.0) * torch.clamp(std, min=1e-300))
+        return torch.where(std > 0, gx, torch.zeros_like(gx)).to(g.dtype)
+
+
+def batch_std(x):
+    """`x.std(dim=0, keepdim=True)` over the GLOBAL batch: the path-length regulariser's `w_styles.std(dim=0)`
+    (histoGAN/histoGAN.py:966-968).  The reference is single-GPU, its statistic spans the whole batch; under data
+    parallelism (dim 0 = this rank's shard) it still does here (_GlobalStd), differentiable like the original."""
+    if not is_dist():
+        return x.std(dim=0, keepdim=True)
+    return _GlobalStd.apply(x)
+
+
 def all_reduce_scalar(value, op='mean', device=None):
     """All-reduce a python float ('mean' | 'max' | 'sum'); identity when not distributed."""
     if not is_dist():

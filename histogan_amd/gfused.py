@@ -92,6 +92,11 @@ def _modulate_bwd(g, x, s, upsample):
 def _torgb(x, s, w, prev):
     B, O, H, W = x.shape
     Cr = w.shape[0]
+    if Cr * O * 4 > 48 * 1024:
+        # (the 8 192-channel blocks of the 1024^2 configuration: hg_torgb_fwd stages w (s + 1) in LDS; there the 1x1 modulated
+        # convolution runs on the matrix kernel with the modulation as its input scale, plus the running-image add)
+        rgb = C.conv_fwd_packed(x, C.pack_weights(w.reshape(Cr, O, 1, 1), C.PACK_FWD), Cr, 1, 1, iscale=s + 1.0)
+        return rgb if prev is None else rgb.add_(prev)
     with on_device(x.device):
         out = torch.empty((B, Cr, H, W), dtype=torch.float32, device=x.device)
         check(lib.hg_torgb_fwd(x.data_ptr(), s.data_ptr(), w.data_ptr(), _ptr(prev), out.data_ptr(), B, O, Cr, H * W, _st(x)),
@@ -335,7 +340,7 @@ def supported(gen, styles_t, nzt, train=True):
         if r.demod or r.kernel != 1 or r.stride != 1 or r.dilation != 1 or r.weight.shape[0] > 4:
             return False
         Cmax = max(b.conv1.weight.shape[0], b.conv1.weight.shape[1])
-        if H > S or B * Cmax * H * H * 4 >= 2 ** 31 or r.weight.shape[0] * r.weight.shape[1] * 4 > 48 * 1024:
+        if H > S or B * Cmax * H * H * 4 >= 2 ** 31:
             return False
         if (b.upsample is not None) != (i != 0) or (b.to_rgb.upsample is not None) != (i != len(gen.blocks) - 1):
             return False

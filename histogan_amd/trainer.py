@@ -766,7 +766,8 @@ class Trainer():
             loss = fake_output.mean()
             gen_loss = loss + histogram_loss
             if apply_path_penalty:
-                std = 0.1 / (w_styles.std(dim=0, keepdim=True) + EPS)
+                # (under data parallelism the statistic is over the GLOBAL batch, as in the single-GPU reference: ddp.batch_std)
+                std = 0.1 / (ddp.batch_std(w_styles) + EPS)
                 w_styles_2 = w_styles + self.rng.randn_like(w_styles) / (std + EPS)
                 pl_images = GAN.G(w_styles_2, h_w_space, noise)
                 pl_lengths = ((pl_images - generated_images) ** 2).mean(dim=(1, 2, 3))

@@ -211,3 +211,91 @@ def test_c5_full_width_discriminator_and_penalty_match_fp64_oracle(gpu_device):
     assert ours <= (2 * ref32 + 1e-6 if ref32 is not None else 1e-4), rec
     del D
     torch.cuda.empty_cache()
+
+
+def test_c5_full_width_generator_matches_fp64_oracle(gpu_device):
+    """The GENERATOR of configs[4] at full width (VERDICT r5 item 4 ii): Generator(1024, 512, network_capacity 16) -- nine
+    blocks, 8 192-channel Winograd / split-K plans on the 4^2 ... 16^2 maps, 1.24 G parameters -- forward + backward at B = 1
+    through the one-node training pass (histogan_amd/gfused.py) against the oracle (oracle/histogan_nets.generator: the
+    reference's per-sample-weight grouped convolution, histoGAN/histoGAN.py:420-440, 529-568) evaluated in fp64 ON THE GPU
+    on aten's native convolution, on the LeakyReLU branches our forward took (oracle_step.LreluMasks: disagreeing elements
+    counted, all rounding-sized).  rgb 1e-5; gradients of styles / hists / every parameter by the 2x criterion on the RMS over
+    all tensors with the same oracle in fp32 as the yardstick, and 1e-4 absolute on that RMS."""
+    from histoGAN import Generator
+    from histogan_amd import gfused
+    from oracle import histogan_nets as N
+    from oracle_step import LreluMasks
+    if torch.cuda.get_device_properties(gpu_device).total_memory < 200 * 2 ** 30:
+        pytest.skip('needs ~100 GB of device memory')
+    torch.manual_seed(78)
+    dev, S_, LAT, B = gpu_device, 1024, 512, 1
+    with torch.device(dev):
+        G = Generator(S_, LAT, network_capacity=16)
+    G = G.to(dev)
+    with torch.no_grad():
+        for m in G.modules():         # HistoGAN._init_weights (reference :686-696)
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
+                torch.nn.init.kaiming_normal_(m.weight, a=0, mode='fan_in', nonlinearity='leaky_relu')
+        for blk in G.blocks:          # the reference zero-initialises the noise layers (:692-696): exercise them
+            blk.to_noise1.weight.normal_(std=0.3); blk.to_noise2.weight.normal_(std=0.3)
+            blk.to_noise1.bias.normal_(std=0.1); blk.to_noise2.bias.normal_(std=0.1)
+    L = G.num_layers
+    assert L == 9 and sum(p.numel() for p in G.parameters()) > 1.2e9
+    names = [n for n, _ in G.named_parameters()]
+    params = dict(G.named_parameters())
+    g = torch.Generator(device='cpu').manual_seed(79)
+    styles = torch.randn(B, L - 2, LAT, generator=g).to(dev).requires_grad_(True)
+    hists = torch.randn(B, 2, LAT, generator=g).to(dev).requires_grad_(True)
+    noise = torch.rand(B, S_, S_, 1, generator=g).to(dev)
+    go = torch.randn(B, 3, S_, S_, generator=g).to(dev)
+    masks = []
+    gfused.STAGE_OBSERVER = lambda out: masks.append(out.detach() > 0)
+    try:
+        rgb = G(styles, hists, noise)
+    finally:
+        gfused.STAGE_OBSERVER = None
+    assert len(masks) == 2 * L, 'the one-node training pass did not run (gfused.supported)'
+    grads = [t.detach() for t in torch.autograd.grad(rgb, [styles, hists] + [params[n] for n in names], go)]
+    rgb = rgb.detach().clone()
+    torch.cuda.empty_cache()
+
+    def oracle(dt):
+        sd = {k: v.detach().to(dt).clone().requires_grad_(True) for k, v in G.state_dict().items()}
+        st, hi = styles.detach().to(dt).requires_grad_(True), hists.detach().to(dt).requires_grad_(True)
+        with torch.backends.cudnn.flags(enabled=False):
+            o = N.generator(sd, st, hi, noise.to(dt), L)
+            gr = torch.autograd.grad(o, [st, hi] + [sd[n] for n in names], go.to(dt))
+        out = o.detach().clone(), [t.detach() for t in gr]
+        del sd, o, gr
+        torch.cuda.empty_cache()
+        return out
+
+    with LreluMasks(masks) as lm:
+        t_rgb, t_gr = oracle(torch.float64)
+    assert lm.k == len(masks) and lm.flips <= 1e-5 * lm.total and lm.flip_margin <= 5e-6, (lm.flips, lm.total, lm.flip_margin)
+    num = lambda gs: float(torch.sqrt(sum(((a.double() - t) ** 2).sum() for a, t in zip(gs, t_gr))))
+    den = float(torch.sqrt(sum((t ** 2).sum() for t in t_gr)))
+    ours = num(grads) / den
+    rec = dict(rgb_ours=_rel(rgb, t_rgb), grad_rms_ours=ours, lrelu_flips=lm.flips, lrelu_total=lm.total,
+               lrelu_flip_margin=lm.flip_margin)
+    ref32 = None
+    try:
+        r_rgb, r_gr = oracle(torch.float32)
+        ref32 = num(r_gr) / den
+        rec.update(rgb_ref32=_rel(r_rgb, t_rgb), grad_rms_ref32=ref32)
+    except RuntimeError as e:
+        rec['ref32_error'] = str(e)[:200]
+        torch.cuda.empty_cache()
+    try:
+        import json, os
+        from conftest import ROOT
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'c5_generator_parity.json'), 'w') as f:
+            json.dump(rec, f, indent=1)
+    except OSError:
+        pass
+    assert rec['rgb_ours'] <= 1e-5, rec
+    assert ours <= 1e-4, rec
+    assert ours <= (2 * ref32 + 1e-6 if ref32 is not None else 1e-4), rec
+    del G
+    torch.cuda.empty_cache()

@@ -70,6 +70,23 @@ def _worker(rank, world, port, q):
             assert ddp.ranks_share_a_device('cuda:0') is True          # (first use for this key: gathers the faked identities)
         finally:
             ddp._device_identity = real
+        # global-batch std of the path-length term (ddp.batch_std): value and gradient of two ranks on halves of a batch ==
+        # one process on the whole batch (loss = mean over ranks of a function of local rows and the global statistic)
+        gen = torch.Generator().manual_seed(3)
+        xa = torch.randn(6, 4, 5, generator=gen, dtype=torch.float64)
+        cw = torch.randn(6, 4, 5, generator=gen, dtype=torch.float64)
+        def loss_of(x, c, std):
+            return ((x + c / (0.1 / (std + 1e-8) + 1e-8)) ** 2).mean()
+        xs = xa[rank * 3:(rank + 1) * 3].clone().requires_grad_(True)
+        lr_ = loss_of(xs, cw[rank * 3:(rank + 1) * 3], ddp.batch_std(xs))
+        lr_.backward()
+        xw = xa.clone().requires_grad_(True)
+        std_w = xw.std(dim=0, keepdim=True)
+        lw = 0.5 * (loss_of(xw[:3], cw[:3], std_w) + loss_of(xw[3:], cw[3:], std_w))
+        lw.backward()
+        assert torch.allclose(ddp.batch_std(xs.detach()), std_w.detach(), rtol=1e-12, atol=1e-14)
+        # rank-averaged gradient convention: this rank's rows of d(mean of rank losses) = local gradient / world
+        assert torch.allclose(xs.grad / 2, xw.grad[rank * 3:(rank + 1) * 3], rtol=1e-10, atol=1e-12)
         q.put((rank, 'ok'))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

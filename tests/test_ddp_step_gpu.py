@@ -105,7 +105,9 @@ def _worker(rank, world, port, step_no, tmp, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('step_no', [1, 4])        # a plain step and a gradient-penalty step
+@pytest.mark.parametrize('step_no', [1, 4, 0])     # a plain step, a gradient-penalty step, the GP + path-length step
+# (step 0: the path-length term's `w_styles.std(dim=0)` is taken over the GLOBAL batch -- ddp.batch_std -- so two ranks on
+# halves of the batch reproduce the single process on the whole of it)
 def test_two_rank_step_equals_single_process(step_no, gpu_device, tmp_path):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
