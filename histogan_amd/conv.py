@@ -26,6 +26,7 @@ _skip_wgrad = False
 # packed on first use from `.wino_src`); a launch takes it when hg_wino_supported says the shape is served and faster.
 WINO = os.environ.get('HG_WINO', '1') != '0'
 _wino_ok = {}
+_wino_used = set()    # keys of registered weights some launch took the Winograd operand of
 
 
 def wino_supported(B, K, N, H, W):
@@ -64,6 +65,9 @@ def _wino_u(wt, mode, B, K, N, H, W):
     if not wino_supported(B, K, N, H, W):
         return None
     u = getattr(wt, 'wino', None)
+    src = getattr(wt, 'pack_src', None)
+    if src is not None and u is not None and u is not False:
+        _wino_used.add(src[2])
     if u is None:
         src = getattr(wt, 'wino_src', None)
         if src is None:
@@ -293,6 +297,11 @@ def _direct_operand(wt):
             check(lib.hg_conv_pack_weights(p.data_ptr(), wt.data_ptr(), Co, Ci, k, mode, _st(p)), 'hg_conv_pack_weights')
         wt.direct_stale = False
         _direct_needed.add(key)
+        if p.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # another stream that takes this operand afterwards sees direct_stale == False: it has to wait for THIS pack
+            # (registered like a group of the batched pack: consumers wait once per stream, _await_pack)
+            cur = torch.cuda.current_stream(p.device)
+            _pack_events.setdefault(_owner_of(p), []).append([cur.record_event(), {cur.cuda_stream}, {key}])
     return wt
 
 
@@ -315,7 +324,11 @@ def _pack_owner(owner, device, launch=True, record_on=None):
             live.append((key, p))
     if not live:
         return False
-    sig = (tuple(k for k, _ in live), frozenset(k for k, _ in live if k in _direct_needed))
+    # A registered 3x3 weight that launches asked the DIRECT operand of and never the Winograd one (the discriminator's stride-2
+    # convolutions, layers hg_wino_supported refuses) gets no Winograd operands from the next plan on: they were 16/9 of the
+    # weight per mode, re-packed every optimizer step for nobody.
+    no_wino = frozenset(k for k, _ in live if k in _direct_needed and k not in _wino_used)
+    sig = (tuple(k for k, _ in live), frozenset(k for k, _ in live if k in _direct_needed), no_wino)
     plan = _multi.get(owner)
     with on_device(device):
         if plan is None or plan['sig'] != sig:
@@ -341,7 +354,7 @@ def _pack_owner(owner, device, launch=True, record_on=None):
                     bufs[key] = (wf, wd, wq)
                     wf.wino = wd.wino = False
                     nf = nd = 0
-                    if WINO and k == 3:        # the Winograd operands of the 3x3 weights (include/hg_wino.h), one more launch
+                    if WINO and k == 3 and key not in no_wino:   # the Winograd operands of the 3x3 weights (include/hg_wino.h), one more launch
                         nf, nd = lib.hg_wino_packed_elems(Co, Ci, PACK_FWD), lib.hg_wino_packed_elems(Co, Ci, PACK_DGRAD)
                         if nf:
                             wf.wino = torch.empty(nf, dtype=torch.float32, device=device)

@@ -1040,15 +1040,23 @@ struct ConvPlan {
 // for 1 / 2 / 3 blocks of the 128x128 tile), and a launch whose block count is not a multiple of (CUs x c) ends in a
 // round at low occupancy that the dispatcher also balances badly (1024 blocks at c = 3: 104 TFLOP/s, at c = 2: 134).
 constexpr size_t kLdsPerCu = 160 * 1024;
+// per-process caches are keyed by the CURRENT device (a process that launches on a second GPU must not plan with the first
+// one's CU count, nor skip the dynamic-LDS attribute there)
+constexpr int kMaxDev = 16;
+inline int cur_dev() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+  return dev;
+}
 inline int num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
+  static int n[kMaxDev] = {0};
+  const int dev = cur_dev();
+  if (!n[dev]) {
     hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
-    if (n <= 0) n = 256;
+    if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n[dev] = pr.multiProcessorCount;
+    if (n[dev] <= 0) n[dev] = 256;
   }
-  return n;
+  return n[dev];
 }
 // *t_out: modelled duration of the launch in units of (one block alone on a CU at the full matrix rate)
 inline int pick_blocks_per_cu(long long nwg, int cmax, double *t_out = nullptr) {

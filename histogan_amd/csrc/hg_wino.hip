@@ -859,15 +859,23 @@ inline int ceil_log2(int v) {
   while ((1 << l) < v) ++l;
   return l;
 }
+// per-process caches are keyed by the CURRENT device (a process that launches on a second GPU must not plan with the first
+// one's CU count, nor skip the dynamic-LDS attribute there)
+constexpr int kMaxDev = 16;
+inline int cur_dev() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+  return dev;
+}
 inline int num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
+  static int n[kMaxDev] = {0};
+  const int dev = cur_dev();
+  if (!n[dev]) {
     hipDeviceProp_t pr;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
-    if (n <= 0) n = 256;
+    if (hipGetDeviceProperties(&pr, dev) == hipSuccess) n[dev] = pr.multiProcessorCount;
+    if (n[dev] <= 0) n[dev] = 256;
   }
-  return n;
+  return n[dev];
 }
 
 // the variant serving N output channels: 0 = 64 ch x 64 tiles (KC 8), 1 = 32 ch x 128 tiles (KC 4)
@@ -961,11 +969,12 @@ template <int TC, int TP, int KC>
 int launch_wino(const WinoArgs &a, const WinoPlan &p, bool fe, hipStream_t st) {
   auto kern = fe ? k_wino<TC, TP, KC, true> : k_wino<TC, TP, KC, false>;
   constexpr size_t lds = 2 * 16 * KC * 32 * TP * sizeof(float);
-  static bool attr[2] = {false, false};
-  if (!attr[fe]) {
+  static bool attr[kMaxDev][2] = {};
+  const int dev = cur_dev();
+  if (!attr[dev][fe]) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr[fe] = true;
+    attr[dev][fe] = true;
   }
   const long long total = p.blocks * a.ksplit;
   static const int persist = getenv("HG_WINO_PERSIST") ? atoi(getenv("HG_WINO_PERSIST")) : 1;
@@ -1094,11 +1103,12 @@ int hg_wino_wgrad(const float *in, const float *gout, float *gw, int32_t B, int3
   a.Np = p.ntiles * 64; a.Kp = p.ktiles * 64;
   hipStream_t st = (hipStream_t)stream;
   constexpr size_t lds = 4 * (size_t)WG_OP * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static bool attr[kMaxDev] = {};
+  const int dev = cur_dev();
+  if (!attr[dev]) {
     hipError_t e = hipFuncSetAttribute((const void *)k_wino_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr = true;
+    attr[dev] = true;
   }
   a.xtiles = p.ktiles * p.ntiles; a.total_blocks = a.xtiles * p.splits;
   static const int xcd = getenv("HG_WINO_XCD") ? atoi(getenv("HG_WINO_XCD")) : 1;

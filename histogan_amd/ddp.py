@@ -43,11 +43,19 @@ def _device_identity(device):
         return (socket.gethostname(), 'cpu', os.getpid())
     pr = torch.cuda.get_device_properties(device)
     index = device.index if device.index is not None else torch.cuda.current_device()
-    # everything that can tell two GPUs apart, whichever of it this torch / driver fills in: two ranks on ONE GPU agree on all
-    # of it, two ranks on different GPUs differ in at least one entry
-    ident = (str(getattr(pr, 'uuid', '')), getattr(pr, 'pci_domain_id', -1), getattr(pr, 'pci_bus_id', -1),
-             getattr(pr, 'pci_device_id', -1), os.environ.get('HIP_VISIBLE_DEVICES', ''), os.environ.get('CUDA_VISIBLE_DEVICES', ''),
-             os.environ.get('ROCR_VISIBLE_DEVICES', ''), index)
+    # The PHYSICAL identity where torch / the driver exposes one: the uuid, or the PCI address.  Visibility masks and the logical
+    # index are NOT part of it then -- two ranks can reach one GPU through different masks (HIP_VISIBLE_DEVICES=0 for one rank,
+    # unset for the other; masks '0,1' and '0', both at index 0) and must still compare equal.  Only when neither is
+    # available does (masks, logical index) stand in.
+    uuid = str(getattr(pr, 'uuid', '') or '')
+    pci = (getattr(pr, 'pci_domain_id', -1), getattr(pr, 'pci_bus_id', -1), getattr(pr, 'pci_device_id', -1))
+    if uuid and set(uuid) - set('0-'):
+        ident = ('uuid', uuid)
+    elif pci[1] >= 0:
+        ident = ('pci',) + pci
+    else:
+        ident = ('mask', os.environ.get('HIP_VISIBLE_DEVICES', ''), os.environ.get('CUDA_VISIBLE_DEVICES', ''),
+                 os.environ.get('ROCR_VISIBLE_DEVICES', ''), index)
     return (socket.gethostname(), 'cuda', str(ident))
 
 
@@ -105,6 +113,14 @@ def _avg_in_collective():
 BUCKETS = max(1, int(os.environ.get('HG_DDP_BUCKETS', '4')))
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class GradAllReduce:
     """Averaging all-reduce of a flat gradient buffer in `chunks` contiguous buckets, asynchronous: `start()` launches all
     of them in order, `wait(i)` makes the current stream wait for bucket i only (`ranges[i]` = its element range),
@@ -118,20 +134,59 @@ class GradAllReduce:
         step = -(-n // c)
         step = -(-step // 1024) * 1024                      # bucket boundaries on 4 KB
         self.ranges = [(lo, min(n, lo + step)) for lo in range(0, n, step)]
+        self._full_ranges = list(self.ranges)
+
+    def _split(self, lo, hi, c):
+        step = -(-(hi - lo) // max(1, c))
+        step = max(1024, -(-step // 1024) * 1024)           # bucket boundaries on 4 KB
+        return [(a, min(hi, a + step)) for a in range(lo, hi, step)]
+
+    def start_early(self, stream):
+        """The all-reduce of the flat buffer's leading convolution-weight region NOW, from `stream`: legal as soon as every one
+        of those weights has its final gradient in its slot (FlatParams.conv_region_final: when the generator's fused backward
+        node returns), while the rest of the backward -- style projections, mapping networks -- is still to run.  83 of the
+        generator side's 99.8 M parameters at C3: the collective that was fully exposed behind the last backward kernel
+         now runs under that tail and under the remaining small buckets.  `start()` then launches only the rest.
+        Returns False (nothing done) when not distributed or a slot of the region was not written directly."""
+        f = self.flat
+        if not is_dist() or self._work or not f.conv_region_final():
+            return False
+        from .conv import side_stream
+        dev = f.grad.device
+        if dev.type == 'cuda':
+            stream.wait_stream(side_stream(dev))                                # the weight gradients and demodulation terms
+            stream.wait_event(torch.cuda.current_stream(dev).record_event())    # slots written on the calling stream (to-RGB)
+        n, hi = f.numel, f.n_conv
+        early = self._split(0, hi, self.chunks)
+        self.ranges = early + (self._split(hi, n, max(1, self.chunks // 2)) if n > hi else [])
+        g = f.grad
+        avg = _avg_in_collective()
+        ctx = torch.cuda.stream(stream) if dev.type == 'cuda' else _NullCtx()
+        with ctx:
+            if not avg:
+                g[:hi].mul_(1.0 / world_size())
+            for lo, up in early:
+                self._work.append(dist.all_reduce(g[lo:up], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, async_op=True))
+        self._early = len(early)
+        return True
 
     def start(self):
         self.flat.gather()
         if not is_dist():
             return
-        if self._work:             # handles of a step that did not get to its wait (an exception in between): drain them
+        early = self.__dict__.pop('_early', 0)
+        if self._work and not early:   # handles of a step that did not get to its wait (an exception in between): drain them
             self.finish()
         g = self.flat.grad
+        if not early:
+            self.ranges = list(self._full_ranges)
+        lo0 = self.ranges[early][0] if early < len(self.ranges) else self.flat.numel
         if _avg_in_collective():
             op = dist.ReduceOp.AVG
         else:
             op = dist.ReduceOp.SUM
-            g.mul_(1.0 / world_size())
-        for lo, hi in self.ranges:
+            g[lo0:].mul_(1.0 / world_size())
+        for lo, hi in self.ranges[early:]:
             self._work.append(dist.all_reduce(g[lo:hi], op=op, async_op=True))
 
     def wait(self, i):

@@ -72,6 +72,21 @@ class FlatParams:
             from .conv import register_grad_slots
             register_grad_slots(self)
 
+    def conv_region_final(self):
+        """True when every parameter of the leading convolution-weight region (n_conv elements) has its gradient of this step
+        in its flat slot, written directly (conv._direct_wgrad, the demodulation term, gfused's to-RGB write) and by nothing
+        else -- the condition under which that region may be reduced / updated before gather()."""
+        if self.n_conv <= 0 or not self.direct_ok or self.grad is None:
+            return False
+        base, off = self.grad.data_ptr(), 0
+        for p in self.params:
+            if off >= self.n_conv:
+                break
+            if base + 4 * off not in self.direct_written or p.grad is not None:
+                return False
+            off += p.numel()
+        return True
+
     def zero_grad(self):
         """Drop the parameter gradients.  With `.grad = None` autograd's AccumulateGrad hands over the incoming gradient
         tensor instead of launching one `grad += new` kernel per parameter into a zeroed buffer; `gather()` then
@@ -176,15 +191,9 @@ class DiffGrad:
         Returns False (nothing done) when a slot of the region was not written directly."""
         f = self.flat
         hi = f.n_conv
-        if hi <= 0 or self.graph_mode or not f.data.is_cuda or getattr(self, '_early', None) is not None or not f.direct_ok:
+        if hi <= 0 or self.graph_mode or not f.data.is_cuda or getattr(self, '_early', None) is not None \
+                or not f.conv_region_final():
             return False
-        base, off = f.grad.data_ptr(), 0
-        for p in f.params:
-            if off >= hi:
-                break
-            if base + 4 * off not in f.direct_written or p.grad is not None:
-                return False
-            off += p.numel()
         from .conv import side_stream
         dev = f.data.device
         stream.wait_stream(side_stream(dev))                       # the weight gradients and demodulation terms

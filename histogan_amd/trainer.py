@@ -72,6 +72,9 @@ GRAPH_GP = os.environ.get('HG_GRAPH_GP', '1') != '0'      # gradient-penalty ste
 # (profiles/r06_ab_early_gopt.json): 865.7 images/s with it, 867.7 without -- the HBM-bound update beside the latency-bound
 # mapping-network backward slows that chain by what it saves at the step boundary; off by default.
 EARLY_GOPT = os.environ.get('HG_EARLY_GOPT', '0') != '0'
+# Data parallelism: the all-reduce of G's convolution-weight gradients (83 of 99.8 M parameters at C3) starts when the
+# generator's fused backward node returns, under the rest of the backward (ddp.GradAllReduce.start_early)
+EARLY_GREDUCE = os.environ.get('HG_EARLY_GREDUCE', '1') != '0'
 LAZY_STATS = os.environ.get('HG_LAZY_STATS', '1') != '0'  # statistics of step n read while step n+1 is queued (0: blocking read-back every step)
 
 
@@ -780,7 +783,9 @@ class Trainer():
                         gen_loss = gen_loss + pl_loss
             gen_loss = gen_loss / acc
             self._mark('g_phase_d_forward_hist_loss')
-            early_opt = (EARLY_GOPT and acc == 1 and not apply_path_penalty and not ddp.is_dist()
+            # at the end of the generator's fused backward node: start the all-reduce of G's convolution-weight gradients
+            # (data parallelism) or -- single process, opt-in -- update them
+            early_opt = ((EARLY_GREDUCE if ddp.is_dist() else EARLY_GOPT) and acc == 1 and not apply_path_penalty
                          and not torch.cuda.is_current_stream_capturing())
             if early_opt:
                 from . import gfused
@@ -878,7 +883,9 @@ class Trainer():
         st = self.__dict__.get('_opt_stream')
         if st is None:
             st = self._opt_stream = torch.cuda.Stream(device=self.device)
-        if GAN.G_opt.step_early(st):
+        if ddp.is_dist():
+            GAN._reduce_g.start_early(st)
+        elif GAN.G_opt.step_early(st):
             with torch.cuda.stream(st):
                 self._early_packed = bool(prepack_async(GAN._flat_g.data))
 

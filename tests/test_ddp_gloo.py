@@ -70,6 +70,31 @@ def _worker(rank, world, port, q):
             assert ddp.ranks_share_a_device('cuda:0') is True          # (first use for this key: gathers the faked identities)
         finally:
             ddp._device_identity = real
+        # early start of the convolution-weight region (GradAllReduce.start_early): the leading 4-d parameters' gradients are
+        # written straight into their flat slots (simulated), reduced first; the rest follows in start(); next step: plain start()
+        from histogan_amd.optim import conv_first
+        ps = [torch.nn.Parameter(torch.zeros(7)), torch.nn.Parameter(torch.zeros(40, 8, 3, 3)), torch.nn.Parameter(torch.zeros(3, 40, 1, 1)),
+              torch.nn.Parameter(torch.zeros(2000))]
+        fe = FlatParams(conv_first(ps))
+        assert fe.n_conv == 40 * 8 * 9 + 120 and fe.params[0] is ps[1]
+        re_ = ddp.GradAllReduce(fe, 2)
+        for step in range(2):
+            fe.zero_grad()
+            off = 0
+            for p_ in fe.params[:2]:
+                fe.grad[off:off + p_.numel()].fill_(float(rank + 1 + step))
+                fe.direct_written.add(fe.grad.data_ptr() + 4 * off)
+                off += p_.numel()
+            assert fe.conv_region_final()
+            if step == 0:
+                assert re_.start_early(None) and len(re_._work) == 2
+            ps[0].grad = torch.full((7,), 10.0 * (rank + 1))
+            ps[3].grad = torch.full((2000,), 100.0 * (rank + 1))
+            re_.start()
+            re_.finish()
+            assert torch.allclose(fe.grad[:fe.n_conv], torch.full((fe.n_conv,), 1.5 + step))
+            assert torch.allclose(ps[0].grad, torch.full((7,), 15.0)) and torch.allclose(ps[3].grad, torch.full((2000,), 150.0))
+            assert re_.ranges[-1][1] == fe.numel and re_.ranges[0][0] == 0
         # global-batch std of the path-length term (ddp.batch_std): value and gradient of two ranks on halves of a batch ==
         # one process on the whole batch (loss = mean over ranks of a function of local rows and the global statistic)
         gen = torch.Generator().manual_seed(3)
