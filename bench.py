@@ -117,7 +117,7 @@ def g_layers(size, cap):
 G_LAYERS = g_layers(256, 16)
 
 
-TRAFFIC_FILE = 'r05_pmc_traffic.json'
+TRAFFIC_FILE = 'r06_pmc_traffic.json'
 
 
 def source_digest(name):
@@ -132,7 +132,7 @@ def source_digest(name):
 
 def recorded_traffic(key):
     """HBM bytes per launch (FETCH_SIZE + WRITE_SIZE) from the committed rocprofv3 --pmc passes of exactly this launch
-    (profiles/r05_pmc_traffic.json 'bench': tools/wino_pmc.sh / conv_traffic.sh / hist_traffic.sh / make_traffic_record_r05.py; FETCH_SIZE x 2
+    (profiles/r06_pmc_traffic.json 'bench': tools/wino_pmc.sh / conv_traffic.sh / hist_traffic.sh / make_traffic_record_rounds.py; FETCH_SIZE x 2
     as calibrated by tools/ubench/fetch_calib.hip, profiles/r05_fetch_calibration.txt).  The record carries the digest of
     the kernel source it was measured on: when the source has changed since, the number is stale and None is reported
     (VERDICT r2 weak #8).  Returns (bytes or None, provenance string)."""

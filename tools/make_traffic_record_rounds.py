@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r05_pmc_traffic.json: FETCH_SIZE / WRITE_SIZE per launch (rocprofv3 --kernel-trace --pmc, separate passes, KB) of
+"""profiles/r<NN>_pmc_traffic.json (round given as the 5th argument, default 06): FETCH_SIZE / WRITE_SIZE per launch (rocprofv3 --kernel-trace --pmc, separate passes, KB) of
 bench.py's roofline launches, stamped with the digest of the kernel source they were measured on (bench.py reports `traffic`
 only while that digest still matches):
   * tools/wino_pmc.sh      <out>/wino_roofline_traffic.txt   hg_wino_conv2d / hg_wino_wgrad at 256 -> 128 channels, 64 x 64, batch 32
@@ -12,7 +12,7 @@ is tallied as 64 B, whatever the lane width (the guide states the factor for 16 
 "as reported", which under-stated the direct kernels' reads by half).  WRITE_SIZE as reported (k_wino's 67 108 864-byte output reads
 65 536.0 KB).  Infinity-Cache hits are counted: this is fabric traffic, an upper bound on HBM traffic.
 
-    python tools/make_traffic_record_r05.py <wino txt> <conv txt> <thr txt> <commit>"""
+    python tools/make_traffic_record_rounds.py <wino txt> <conv txt> <thr txt> <commit> [round]"""
 import hashlib
 import json
 import os
@@ -78,7 +78,8 @@ t['algorithmic_bytes_fwd_bwd'] = 78643200
 bench['thr_fwd_bwd_c2'] = dict(fetch_bytes=fetch, write_bytes=write, comment='k_thr_fwd_lean + k_hist_finish + k_thr_bwd_lean; FETCH_SIZE x 2',
                                source='hg_hist.hip', source_sha16=digest('hg_hist.hip'), commit=commit)
 rec = dict(_note=' '.join(__doc__.split('Correction: ')[1].split('\n\n')[0].split()), thresholding_b32_256x256_h64=t, bench=bench)
-with open(os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json'), 'w') as f:
+rnd = sys.argv[5] if len(sys.argv) > 5 else '06'
+with open(os.path.join(ROOT, 'profiles', f'r{rnd}_pmc_traffic.json'), 'w') as f:
     json.dump(rec, f, indent=1)
 for k, v in bench.items():
     print(f'{k:30s} fetch {v["fetch_bytes"] / 1e6:8.1f} MB  write {v["write_bytes"] / 1e6:7.1f} MB')
