@@ -428,7 +428,8 @@ class Trainer():
 
     def _w_and_hw(self, style, hist_batch):
         GAN = self.GAN
-        if (H_SIDE and hist_batch.is_cuda and (H_SIDE_GRAD or not torch.is_grad_enabled())
+        if (H_SIDE and hist_batch.is_cuda
+                and ((H_SIDE_GRAD and self.__dict__.get('_extra_streams_ok', True)) or not torch.is_grad_enabled())
                 and not torch.cuda.is_current_stream_capturing()):
             # the histogram vectorizer beside the mapping network instead of behind it -- two independent chains of 8 small
             # serial GEMMs at the head of the generator forward; with autograd recording, the engine runs each chain's
@@ -639,6 +640,7 @@ class Trainer():
         else:
             ddp_ok = not ddp.ranks_share_a_device(dev)        # (collective on first use: every rank is in its first step here)
         overlap_g = G_OVERLAP and acc == 1 and ddp_ok
+        self._extra_streams_ok = ddp_ok       # (ranks sharing a GPU: no further streams either -- H beside S under autograd, early all-reduce)
         if overlap_g and not getattr(self, '_warn_off', False):
             # parameters live on the default stream, part of the graph now runs on another one: the engine's stream
             # hand-over is intended
@@ -785,7 +787,8 @@ class Trainer():
             self._mark('g_phase_d_forward_hist_loss')
             # at the end of the generator's fused backward node: start the all-reduce of G's convolution-weight gradients
             # (data parallelism) or -- single process, opt-in -- update them
-            early_opt = ((EARLY_GREDUCE if ddp.is_dist() else EARLY_GOPT) and acc == 1 and not apply_path_penalty
+            early_opt = ((EARLY_GREDUCE and self.__dict__.get('_extra_streams_ok', True) if ddp.is_dist() else EARLY_GOPT)
+                         and acc == 1 and not apply_path_penalty
                          and not torch.cuda.is_current_stream_capturing())
             if early_opt:
                 from . import gfused
