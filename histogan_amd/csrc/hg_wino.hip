@@ -24,6 +24,10 @@
 #include "../../include/hg_conv.h"
 #include "../../include/hg_wino.h"
 
+#ifndef HG_WINO_BPIPE
+#define HG_WINO_BPIPE 1
+#endif
+
 namespace {
 
 constexpr unsigned kOOB = 0xFFFFFFFFu;
@@ -215,6 +219,34 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
   auto mfma_chunk = [&](int buf, auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
     const float *Vc = smem + buf * VSZ + lk * TB + lm;
+#if HG_WINO_BPIPE
+    // B operands one MFMA step ahead (the two-slot pipeline of k_conv, hg_conv.hip): the LDS read of step s + 1 is issued in
+    // front of the MFMAs of step s.  The compiler's own order reads a step's operands right in front of its MFMAs, into the A
+    // registers the previous step released: a full LDS round trip per group of TC x TP MFMAs, exposed whenever the SIMD's
+    // other wave is not ready -- under oldest-first arbitration that is the second half of every phase.
+    constexpr int STEPS = KC;          // 2 positions x KC / 2 k steps
+    float bv[2][TP];
+    auto ldb = [&](int st, int slot) __attribute__((always_inline)) {
+      const int x2 = st / (KC / 2), ks = st % (KC / 2);
+#pragma unroll
+      for (int j = 0; j < TP; ++j) bv[slot][j] = Vc[((2 * wave + x2) * KC + 2 * ks) * TB + 32 * j];
+    };
+    constexpr int DSN = (TP + 1) / 2;  // ds_read2_b32 per step
+    ldb(0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, DSN, 0);
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) {
+      const int x2 = st / (KC / 2), ks = st % (KC / 2);
+      if (st + 1 < STEPS) ldb(st + 1, (st + 1) & 1);
+#pragma unroll
+      for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TP; ++j)
+          acc[x2][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[S][x2][ks * TC + i], bv[st & 1][j], acc[x2][i][j], 0, 0, 0);
+      if (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, DSN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TC * TP, 0);
+    }
+#else
 #pragma unroll
     for (int x2 = 0; x2 < 2; ++x2)
 #pragma unroll
@@ -228,6 +260,7 @@ __global__ __launch_bounds__(512) void k_wino(const WinoArgs a) {
           for (int j = 0; j < TP; ++j)
             acc[x2][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[S][x2][ks * TC + i], bv[j], acc[x2][i][j], 0, 0, 0);
       }
+#endif
   };
   auto clampc = [&](int c) __attribute__((always_inline)) { return c < c_end ? c : c_end - 1; };
 #define HG_WINO_BARRIER()               \
